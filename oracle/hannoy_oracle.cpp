@@ -1,0 +1,1187 @@
+/*
+ * hannoy_oracle.cpp — CPU restatement of hannoy's HNSW build hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see hannoy_oracle.h).  Plain, single-file C++17;
+ * every function cites the reference file:line it follows (paths relative to
+ * /root/reference/).  Compile with -ffp-contract=off: every fused multiply-add
+ * below is an explicit fmaf() exactly where the reference uses
+ * _mm256_fmadd_ps, and nowhere else.
+ */
+#include "hannoy_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#define ORC_HAVE_AVX 1
+#else
+#define ORC_HAVE_AVX 0
+#endif
+
+namespace {
+
+inline uint32_t f32_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+inline float loadf(const void *p, size_t i) {
+  float f;
+  std::memcpy(&f, (const uint8_t *)p + 4 * i, 4);
+  return f;
+}
+inline uint64_t load64(const void *p, size_t i) {
+  uint64_t w;
+  std::memcpy(&w, (const uint8_t *)p + 8 * i, 8);
+  return w;
+}
+
+/* ------------------------------------------------------------------ */
+/* src/spaces/simple_avx.rs — scalar emulation of the AVX+FMA kernels  */
+/* ------------------------------------------------------------------ */
+
+/* simple_avx.rs:8-13 hsum256_ps_avx on 8 lanes acc[0..8) */
+inline float hsum256_emul(const float *x) {
+  float x128[4], x64[2];
+  for (int k = 0; k < 4; k++) x128[k] = x[4 + k] + x[k]; /* extractf128(x,1) + cast128(x) */
+  for (int k = 0; k < 2; k++) x64[k] = x128[k] + x128[k + 2]; /* x128 + movehl(x128,x128) */
+  return x64[0] + x64[1]; /* add_ss(x64, shuffle(x64, 0x55)) */
+}
+/* simple_sse.rs:10-14 hsum128_ps_sse */
+inline float hsum128_emul(const float *x) {
+  float x64[2];
+  for (int k = 0; k < 2; k++) x64[k] = x[k] + x[k + 2];
+  return x64[0] + x64[1];
+}
+
+/* simple_avx.rs:69-110 dot_similarity_avx */
+float dot_avx_emul(const void *a, const void *b, size_t n) {
+  size_t m = n - (n % 32);
+  float acc[32];
+  for (int j = 0; j < 32; j++) acc[j] = 0.0f;
+  for (size_t i = 0; i < m; i += 32)
+    for (int j = 0; j < 32; j++) acc[j] = fmaf(loadf(a, i + j), loadf(b, i + j), acc[j]);
+  float result = hsum256_emul(acc) + hsum256_emul(acc + 8) + hsum256_emul(acc + 16) +
+                 hsum256_emul(acc + 24);
+  for (size_t i = m; i < n; i++) {
+    float p = loadf(a, i) * loadf(b, i); /* result += a * b — unfused */
+    result += p;
+  }
+  return result;
+}
+/* simple_avx.rs:17-65 euclid_similarity_avx */
+float euclid_avx_emul(const void *a, const void *b, size_t n) {
+  size_t m = n - (n % 32);
+  float acc[32];
+  for (int j = 0; j < 32; j++) acc[j] = 0.0f;
+  for (size_t i = 0; i < m; i += 32)
+    for (int j = 0; j < 32; j++) {
+      float d = loadf(a, i + j) - loadf(b, i + j);
+      acc[j] = fmaf(d, d, acc[j]);
+    }
+  float result = hsum256_emul(acc) + hsum256_emul(acc + 8) + hsum256_emul(acc + 16) +
+                 hsum256_emul(acc + 24);
+  for (size_t i = m; i < n; i++) {
+    float d = loadf(a, i) - loadf(b, i);
+    float p = d * d; /* (a - b).powi(2) */
+    result += p;
+  }
+  return result;
+}
+/* simple_sse.rs:64-110 dot_similarity_sse (mul then add, unfused) */
+float dot_sse_emul(const void *a, const void *b, size_t n) {
+  size_t m = n - (n % 16);
+  float acc[16];
+  for (int j = 0; j < 16; j++) acc[j] = 0.0f;
+  for (size_t i = 0; i < m; i += 16)
+    for (int j = 0; j < 16; j++) {
+      float p = loadf(a, i + j) * loadf(b, i + j);
+      acc[j] = p + acc[j];
+    }
+  float result =
+      hsum128_emul(acc) + hsum128_emul(acc + 4) + hsum128_emul(acc + 8) + hsum128_emul(acc + 12);
+  for (size_t i = m; i < n; i++) {
+    float p = loadf(a, i) * loadf(b, i);
+    result += p;
+  }
+  return result;
+}
+/* simple_sse.rs:17-61 euclid_similarity_sse */
+float euclid_sse_emul(const void *a, const void *b, size_t n) {
+  size_t m = n - (n % 16);
+  float acc[16];
+  for (int j = 0; j < 16; j++) acc[j] = 0.0f;
+  for (size_t i = 0; i < m; i += 16)
+    for (int j = 0; j < 16; j++) {
+      float d = loadf(a, i + j) - loadf(b, i + j);
+      float p = d * d;
+      acc[j] = p + acc[j];
+    }
+  float result =
+      hsum128_emul(acc) + hsum128_emul(acc + 4) + hsum128_emul(acc + 8) + hsum128_emul(acc + 12);
+  for (size_t i = m; i < n; i++) {
+    float d = loadf(a, i) - loadf(b, i);
+    float p = d * d;
+    result += p;
+  }
+  return result;
+}
+/* simple.rs:81-83 dot_product_non_optimized / :49-51 euclidean_distance_non_optimized */
+float dot_scalar(const void *a, const void *b, size_t n) {
+  float s = 0.0f;
+  for (size_t i = 0; i < n; i++) {
+    float p = loadf(a, i) * loadf(b, i);
+    s = s + p;
+  }
+  return s;
+}
+float euclid_scalar(const void *a, const void *b, size_t n) {
+  float s = 0.0f;
+  for (size_t i = 0; i < n; i++) {
+    float d = loadf(a, i) - loadf(b, i);
+    float p = d * d;
+    s = s + p;
+  }
+  return s;
+}
+
+#if ORC_HAVE_AVX
+/* The same two kernels with the real intrinsics (bit-identical to the
+ * emulation above; used for speed in the CPU baseline). */
+inline float hsum256_real(__m256 x) {
+  __m128 x128 = _mm_add_ps(_mm256_extractf128_ps(x, 1), _mm256_castps256_ps128(x));
+  __m128 x64 = _mm_add_ps(x128, _mm_movehl_ps(x128, x128));
+  __m128 x32 = _mm_add_ss(x64, _mm_shuffle_ps(x64, x64, 0x55));
+  return _mm_cvtss_f32(x32);
+}
+float dot_avx_real(const void *a, const void *b, size_t n) {
+  size_t m = n - (n % 32);
+  const float *p1 = (const float *)a, *p2 = (const float *)b;
+  __m256 s1 = _mm256_setzero_ps(), s2 = s1, s3 = s1, s4 = s1;
+  for (size_t i = 0; i < m; i += 32) {
+    s1 = _mm256_fmadd_ps(_mm256_loadu_ps(p1 + i), _mm256_loadu_ps(p2 + i), s1);
+    s2 = _mm256_fmadd_ps(_mm256_loadu_ps(p1 + i + 8), _mm256_loadu_ps(p2 + i + 8), s2);
+    s3 = _mm256_fmadd_ps(_mm256_loadu_ps(p1 + i + 16), _mm256_loadu_ps(p2 + i + 16), s3);
+    s4 = _mm256_fmadd_ps(_mm256_loadu_ps(p1 + i + 24), _mm256_loadu_ps(p2 + i + 24), s4);
+  }
+  float result = hsum256_real(s1) + hsum256_real(s2) + hsum256_real(s3) + hsum256_real(s4);
+  for (size_t i = m; i < n; i++) {
+    float p = loadf(a, i) * loadf(b, i);
+    result += p;
+  }
+  return result;
+}
+float euclid_avx_real(const void *a, const void *b, size_t n) {
+  size_t m = n - (n % 32);
+  const float *p1 = (const float *)a, *p2 = (const float *)b;
+  __m256 s1 = _mm256_setzero_ps(), s2 = s1, s3 = s1, s4 = s1;
+  for (size_t i = 0; i < m; i += 32) {
+    __m256 d1 = _mm256_sub_ps(_mm256_loadu_ps(p1 + i), _mm256_loadu_ps(p2 + i));
+    s1 = _mm256_fmadd_ps(d1, d1, s1);
+    __m256 d2 = _mm256_sub_ps(_mm256_loadu_ps(p1 + i + 8), _mm256_loadu_ps(p2 + i + 8));
+    s2 = _mm256_fmadd_ps(d2, d2, s2);
+    __m256 d3 = _mm256_sub_ps(_mm256_loadu_ps(p1 + i + 16), _mm256_loadu_ps(p2 + i + 16));
+    s3 = _mm256_fmadd_ps(d3, d3, s3);
+    __m256 d4 = _mm256_sub_ps(_mm256_loadu_ps(p1 + i + 24), _mm256_loadu_ps(p2 + i + 24));
+    s4 = _mm256_fmadd_ps(d4, d4, s4);
+  }
+  float result = hsum256_real(s1) + hsum256_real(s2) + hsum256_real(s3) + hsum256_real(s4);
+  for (size_t i = m; i < n; i++) {
+    float d = loadf(a, i) - loadf(b, i);
+    float p = d * d;
+    result += p;
+  }
+  return result;
+}
+#endif
+
+/* simple.rs:53-79 dot_product dispatch (x86_64 host with avx+fma+sse) */
+float dot_x86(const void *a, const void *b, size_t n) {
+  if (n >= 32) {
+#if ORC_HAVE_AVX
+    return dot_avx_real(a, b, n);
+#else
+    return dot_avx_emul(a, b, n);
+#endif
+  }
+  if (n >= 16) return dot_sse_emul(a, b, n);
+  return dot_scalar(a, b, n);
+}
+/* simple.rs:19-47 euclidean_distance dispatch */
+float euclid_x86(const void *a, const void *b, size_t n) {
+  if (n >= 32) {
+#if ORC_HAVE_AVX
+    return euclid_avx_real(a, b, n);
+#else
+    return euclid_avx_emul(a, b, n);
+#endif
+  }
+  if (n >= 16) return euclid_sse_emul(a, b, n);
+  return euclid_scalar(a, b, n);
+}
+
+/* ------------------------------------------------------------------ */
+/* WAVE order: restatement of the HIP fast path            */
+/* ------------------------------------------------------------------ */
+inline uint32_t pow2ceil(uint32_t x) {
+  uint32_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+inline uint32_t wave_lpr(uint32_t dim) {
+  uint32_t dim4 = (dim + 3) / 4;
+  uint32_t l = pow2ceil(dim4);
+  if (l < 8) l = 8;
+  if (l > 64) l = 64;
+  return l;
+}
+enum { WOP_DOT = 0, WOP_EUCLID = 1, WOP_MANHATTAN = 2 };
+float wave_reduce(int op, const void *a, const void *b, uint32_t dim) {
+  uint32_t dim4 = (dim + 3) / 4, lpr = wave_lpr(dim);
+  uint32_t nch = (dim4 + lpr - 1) / lpr;
+  float v[64];
+  for (uint32_t t = 0; t < lpr; t++) {
+    float acc = 0.0f;
+    for (uint32_t c = 0; c < nch; c++) {
+      uint32_t f = c * lpr + t;
+      if (f >= dim4) continue;
+      for (uint32_t j = 0; j < 4; j++) {
+        uint32_t e = 4 * f + j;
+        float x = e < dim ? loadf(a, e) : 0.0f, y = e < dim ? loadf(b, e) : 0.0f;
+        if (op == WOP_DOT) {
+          acc = fmaf(x, y, acc);
+        } else if (op == WOP_EUCLID) {
+          float d = x - y;
+          acc = fmaf(d, d, acc);
+        } else {
+          float d = fabsf(x - y);
+          acc = acc + d;
+        }
+      }
+    }
+    v[t] = acc;
+  }
+  for (uint32_t off = lpr / 2; off >= 1; off >>= 1) {
+    float w[64];
+    for (uint32_t t = 0; t < lpr; t++) w[t] = v[t] + v[t ^ off];
+    for (uint32_t t = 0; t < lpr; t++) v[t] = w[t];
+  }
+  return v[0];
+}
+
+/* ------------------------------------------------------------------ */
+/* codecs                                                              */
+/* ------------------------------------------------------------------ */
+inline bool is_binary_metric(int metric) { return metric >= ORC_HAMMING; }
+inline size_t vec_bytes(int metric, uint32_t dim) {
+  if (is_binary_metric(metric)) return (size_t)((dim + 63) / 64) * 8; /* binary.rs:80-94 pads to u64 words */
+  return (size_t)dim * 4;                                             /* f32.rs:9-55 */
+}
+inline size_t hdr_bytes(int metric) {
+  return metric == ORC_HAMMING ? 8 : 4; /* hamming.rs:21-25 idx: usize ; others one f32 */
+}
+
+/* popcount(u ^ v) over the whole vector. hamming.rs:55-85 works on u64 words + byte tail
+ * (no tail: codecs pad to 8 B); the BQ kernels go byte by byte — same total. */
+inline uint32_t xor_popcount(const void *u, const void *v, size_t bytes) {
+  uint32_t c = 0;
+  size_t w = bytes / 8;
+  for (size_t i = 0; i < w; i++) c += (uint32_t)__builtin_popcountll(load64(u, i) ^ load64(v, i));
+  const uint8_t *ub = (const uint8_t *)u, *vb = (const uint8_t *)v;
+  for (size_t i = w * 8; i < bytes; i++) c += (uint32_t)__builtin_popcount((unsigned)(ub[i] ^ vb[i]));
+  return c;
+}
+
+/* simple.rs:119-131 dot_product_binary_quantized: per byte ones(!(u^v)) - zeros(!(u^v)) */
+inline float bq_dot(const void *u, const void *v, size_t bytes) {
+  int32_t pop = (int32_t)xor_popcount(u, v, bytes);
+  int32_t bits = (int32_t)(bytes * 8);
+  return (float)(bits - 2 * pop);
+}
+
+struct Dist {
+  int metric;
+  int order;
+  uint32_t dim;
+  size_t vbytes;
+
+  float f32_dot(const void *a, const void *b) const {
+    return order == ORC_ORDER_X86 ? dot_x86(a, b, dim) : wave_reduce(WOP_DOT, a, b, dim);
+  }
+  /* D::distance(p, q) */
+  float operator()(const void *pv, const void *ph, const void *qv, const void *qh) const {
+    switch (metric) {
+      case ORC_COSINE: { /* cosine.rs:40-56 */
+        float pn = loadf(ph, 0), qn = loadf(qh, 0);
+        float pq = f32_dot(pv, qv);
+        float pnqn = pn * qn;
+        if (pnqn > 1.1920929e-07f /* f32::EPSILON */) {
+          float c = pq / pnqn;
+          /* f32::clamp(-1, 1): NaN stays NaN */
+          if (c < -1.0f) c = -1.0f;
+          if (c > 1.0f) c = 1.0f;
+          return (1.0f - c) / 2.0f;
+        }
+        return 0.0f;
+      }
+      case ORC_EUCLIDEAN: /* euclidean.rs:42-44 */
+        return order == ORC_ORDER_X86 ? euclid_x86(pv, qv, dim)
+                                      : wave_reduce(WOP_EUCLID, pv, qv, dim);
+      case ORC_MANHATTAN: { /* manhattan.rs:41-43 scalar left-to-right */
+        if (order == ORC_ORDER_WAVE) return wave_reduce(WOP_MANHATTAN, pv, qv, dim);
+        float s = 0.0f;
+        for (uint32_t i = 0; i < dim; i++) {
+          float d = fabsf(loadf(pv, i) - loadf(qv, i));
+          s = s + d;
+        }
+        return s;
+      }
+      case ORC_HAMMING: { /* hamming.rs:44-47 */
+        float d = (float)xor_popcount(pv, qv, vbytes);
+        return d / (float)(vbytes * 8); /* Binary::len = bytes/8*64, binary.rs:67-69 */
+      }
+      case ORC_BQ_COSINE: { /* binary_quantized_cosine.rs:44-59 */
+        float pn = loadf(ph, 0), qn = loadf(qh, 0);
+        float pq = bq_dot(pv, qv, vbytes);
+        float pnqn = pn * qn;
+        if (pnqn != 0.0f) {
+          float c = pq / pnqn;
+          return (1.0f - c) / 2.0f;
+        }
+        return 0.0f;
+      }
+      case ORC_BQ_EUCLIDEAN: /* binary_quantized_euclidean.rs:76-83 */
+        return (float)(xor_popcount(pv, qv, vbytes) * 4u);
+      case ORC_BQ_MANHATTAN: /* binary_quantized_manhattan.rs:72-79 */
+        return (float)(xor_popcount(pv, qv, vbytes) * 2u);
+    }
+    return 0.0f;
+  }
+};
+
+/* ------------------------------------------------------------------ */
+/* graph state                                                         */
+/* ------------------------------------------------------------------ */
+struct Link {
+  float d;
+  uint32_t id; /* dense slot */
+};
+/* ordered_float.rs:25-29 + tuple order of ScoredLink (hnsw.rs:30) */
+inline uint64_t link_key(const Link &l) { return ((uint64_t)f32_bits(l.d) << 32) | l.id; }
+
+struct NodeList {
+  std::vector<Link> links;       /* NodeState<M0>.links (hnsw.rs:33-35) */
+  std::atomic<uint8_t> lock{0};  /* stands in for papaya's per-key CAS (hnsw.rs:555) */
+  std::atomic<uint8_t> present{0};
+};
+
+struct Builder {
+  orc_opts o;
+  orc_items it;
+  Dist dist;
+  uint32_t n = 0;
+  std::vector<uint8_t> level;
+  uint32_t max_level = 0;
+  std::vector<uint32_t> entry_points;               /* slots, ascending */
+  std::vector<std::vector<int32_t>> idx;            /* [layer][slot] -> list index or -1 */
+  std::vector<std::unique_ptr<NodeList[]>> lists;   /* [layer][list index] */
+  std::vector<std::vector<uint32_t>> owner;         /* [layer][list index] -> slot */
+  std::atomic<uint64_t> n_evals{0}, n_links{0};
+  bool threaded = false;
+
+  const uint8_t *vec(uint32_t s) const { return (const uint8_t *)it.vectors + (size_t)s * it.stride; }
+  const uint8_t *hdr(uint32_t s) const {
+    return (const uint8_t *)it.headers + (size_t)s * it.header_size;
+  }
+  float d_items(uint32_t a, uint32_t b, uint64_t &ctr) const {
+    ctr++;
+    return dist(vec(a), hdr(a), vec(b), hdr(b));
+  }
+  uint32_t cap(uint32_t layer_or_level) const { return layer_or_level == 0 ? o.M0 : o.M; }
+
+  NodeList *list(uint32_t layer, uint32_t slot) {
+    if (layer >= idx.size()) return nullptr;
+    int32_t li = idx[layer][slot];
+    return li < 0 ? nullptr : &lists[layer][li];
+  }
+  void lock(NodeList *l) {
+    if (!threaded) return;
+    while (l->lock.exchange(1, std::memory_order_acquire)) {
+    }
+  }
+  void unlock(NodeList *l) {
+    if (!threaded) return;
+    l->lock.store(0, std::memory_order_release);
+  }
+};
+
+struct Scratch {
+  std::vector<uint32_t> stamp;
+  uint32_t epoch = 0;
+  uint64_t evals = 0;
+  std::vector<uint32_t> nbuf;
+  void begin(uint32_t n) {
+    if (stamp.size() != n) {
+      stamp.assign(n, 0);
+      epoch = 0;
+    }
+    if (++epoch == 0) {
+      std::fill(stamp.begin(), stamp.end(), 0);
+      epoch = 1;
+    }
+  }
+  /* RoaringBitmap::insert → true if newly inserted */
+  bool visit(uint32_t s) {
+    if (stamp[s] == epoch) return false;
+    stamp[s] = epoch;
+    return true;
+  }
+};
+
+/* candidates: BinaryHeap<(Reverse<OrderedFloat>, ItemId)> (hnsw.rs:469): max-heap, so the top is
+ * the smallest distance and, among equal distances, the LARGEST id. */
+struct CandLess {
+  bool operator()(const Link &a, const Link &b) const {
+    uint32_t da = f32_bits(a.d), db = f32_bits(b.d);
+    if (da != db) return da > db; /* Reverse */
+    return a.id < b.id;
+  }
+};
+
+/* hnsw.rs:460-518 walk_layer; returns res as a vector sorted ascending by (bits(d), id) */
+template <class QDist>
+void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint32_t> &eps,
+                uint32_t layer, size_t ef, std::vector<Link> &res) {
+  std::priority_queue<Link, std::vector<Link>, CandLess> cand;
+  res.clear();
+  S.begin(B.n);
+  auto res_insert = [&](const Link &l) {
+    uint64_t k = link_key(l);
+    auto pos = std::lower_bound(res.begin(), res.end(), k,
+                                [](const Link &a, uint64_t key) { return link_key(a) < key; });
+    res.insert(pos, l);
+  };
+  for (uint32_t ep : eps) { /* :474-481 — no capacity check on res here */
+    Link l{qd(ep, S.evals), ep};
+    cand.push(l);
+    res_insert(l);
+    S.visit(ep);
+  }
+  while (!cand.empty()) {
+    float f = cand.top().d;
+    float f_max = res.back().d; /* res.peek_max() :484 */
+    if (f > f_max) break;       /* raw f32 compare :485 */
+    uint32_t c = cand.top().id;
+    cand.pop();
+    /* get_neighbours :428-456 — fresh DB: no on-disk links, in-memory list in insertion order */
+    S.nbuf.clear();
+    if (NodeList *nl = B.list(layer, c)) {
+      B.lock(nl);
+      for (const Link &l : nl->links) S.nbuf.push_back(l.id);
+      B.unlock(nl);
+    }
+    for (uint32_t p : S.nbuf) {
+      if (!S.visit(p)) continue; /* :493 */
+      float d = qd(p, S.evals);  /* :503 */
+      if (res.size() < ef || d < f_max) { /* :505, f_max captured once per pop */
+        Link l{d, p};
+        cand.push(l);
+        if (res.size() == ef) { /* push_pop_max :508-509 */
+          res_insert(l);
+          res.pop_back();
+        } else {
+          res_insert(l); /* :511 */
+        }
+      }
+    }
+  }
+}
+
+/* hnsw.rs:565-597 robust_prune */
+void robust_prune(Builder &B, std::vector<Link> cands, uint32_t cap, uint64_t &evals,
+                  std::vector<Link> &selected) {
+  std::sort(cands.begin(), cands.end(),
+            [](const Link &a, const Link &b) { return link_key(a) < link_key(b); });
+  selected.clear();
+  for (const Link &c : cands) { /* pop from the back of the descending sort = ascending */
+    if (selected.size() == cap) break;
+    bool ok = true;
+    for (const Link &i : selected) {
+      float d = B.d_items(c.id, i.id, evals);
+      float da = d * B.o.alpha;
+      if (f32_bits(da) < f32_bits(c.d)) { /* OrderedFloat(d*alpha) < dist_to_query :585 */
+        ok = false;
+        break;
+      }
+    }
+    if (ok) selected.push_back(c);
+  }
+}
+
+/* hnsw.rs:523-560 add_link */
+void add_link(Builder &B, uint32_t p, Link q, uint32_t layer, uint64_t &evals) {
+  if (p == q.id) return;              /* :530 */
+  NodeList *nl = B.list(layer, p);    /* :534 layer missing → no-op */
+  if (!nl) return;
+  B.lock(nl);
+  nl->present.store(1, std::memory_order_relaxed);
+  uint32_t cap = B.cap(layer); /* :540 — the layer being linked */
+  if (nl->links.size() < cap) {
+    nl->links.push_back(q); /* :542-545, no dedup */
+  } else {
+    std::vector<Link> pruned; /* :547-552 — q itself is dropped */
+    robust_prune(B, nl->links, cap, evals, pruned);
+    nl->links.swap(pruned);
+  }
+  B.unlock(nl);
+}
+
+/* hnsw.rs:419-424 add_in_layers_below */
+void register_item(Builder &B, uint32_t slot, uint32_t level) {
+  for (uint32_t l = 0; l <= level && l < B.idx.size(); l++)
+    if (NodeList *nl = B.list(l, slot)) nl->present.store(1, std::memory_order_relaxed);
+}
+
+struct Selection {
+  std::vector<std::vector<Link>> per_layer; /* index = layer */
+};
+
+/* hnsw.rs:291-328 insert, split into its read-only half (search + prune) ... */
+void insert_search(Builder &B, Scratch &S, uint32_t q, uint32_t level, Selection &out) {
+  std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end()); /* :298 */
+  auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
+  std::vector<Link> res;
+  for (uint32_t l = B.max_level; l > level; l--) { /* :303-307 greedy, ef = 1 */
+    walk_layer(B, S, qd, eps, l, 1, res);
+    eps.assign(1, res.front().id); /* peek_min */
+  }
+  out.per_layer.assign(level + 1, {});
+  for (int32_t l = (int32_t)level; l >= 0; l--) { /* :312-325 */
+    walk_layer(B, S, qd, eps, (uint32_t)l, B.o.ef_construction, res);
+    robust_prune(B, res, B.cap(level) /* NB item's top level, :317 */, S.evals, out.per_layer[l]);
+    eps.clear();
+    for (const Link &s : out.per_layer[l]) eps.push_back(s.id);
+  }
+}
+/* ... and its mutating half (:316-324) */
+void insert_apply(Builder &B, uint32_t q, uint32_t level, const Selection &sel, uint64_t &evals,
+                  uint64_t &links) {
+  for (int32_t l = (int32_t)level; l >= 0; l--)
+    for (const Link &s : sel.per_layer[l]) {
+      add_link(B, q, s, (uint32_t)l, evals);
+      add_link(B, s.id, Link{s.d, q}, (uint32_t)l, evals);
+      links += 2; /* build_stats.incr_link_count(2) :323 */
+    }
+}
+
+} // namespace
+
+struct orc_graph {
+  std::vector<uint32_t> rec_item; /* item ids */
+  std::vector<uint8_t> rec_layer;
+  std::vector<uint64_t> offsets;
+  std::vector<uint32_t> nbrs; /* item ids, ascending unique */
+  std::vector<uint64_t> raw_offsets;
+  std::vector<uint32_t> raw_nbrs;
+  std::vector<float> raw_dists;
+  std::vector<uint32_t> entry_points; /* item ids */
+  uint32_t max_level = 0;
+  uint64_t n_evals = 0, n_links = 0;
+};
+
+extern "C" {
+
+uint32_t orc_batch_size(double frac, uint32_t bmax, uint64_t n_done) {
+  if (bmax == 0) return 1;
+  double b = std::floor(frac * (double)n_done);
+  if (b < 1.0) b = 1.0;
+  if (b > (double)bmax) b = (double)bmax;
+  return (uint32_t)b;
+}
+
+size_t orc_vector_bytes(int32_t metric, uint32_t dim) { return vec_bytes(metric, dim); }
+size_t orc_header_bytes(int32_t metric) { return hdr_bytes(metric); }
+
+void orc_encode_vector(int32_t metric, uint32_t dim, const float *v, void *out) {
+  if (!is_binary_metric(metric)) {
+    std::memcpy(out, v, (size_t)dim * 4);
+    return;
+  }
+  uint8_t *o = (uint8_t *)out;
+  for (uint32_t base = 0; base < dim; base += 64) {
+    uint64_t word = 0;
+    uint32_t cnt = std::min<uint32_t>(64, dim - base);
+    for (int32_t k = (int32_t)cnt - 1; k >= 0; k--) { /* chunk.iter().rev() */
+      word <<= 1;
+      uint32_t bits = f32_bits(v[base + k]);
+      if (metric == ORC_HAMMING)
+        word += (bits < 0x80000000u && bits > 0u) ? 1 : 0; /* binary.rs:87-89 */
+      else
+        word += (bits >> 31) == 0 ? 1 : 0; /* is_sign_positive, binary_quantized.rs:86 */
+    }
+    std::memcpy(o, &word, 8); /* to_ne_bytes */
+    o += 8;
+  }
+}
+
+void orc_make_header(int32_t metric, uint32_t dim, const void *vb, void *out) {
+  switch (metric) {
+    case ORC_COSINE: { /* cosine.rs:36-38,58-60: norm = sqrt(dot(v,v)) */
+      float n = sqrtf(dot_x86(vb, vb, dim));
+      std::memcpy(out, &n, 4);
+      break;
+    }
+    case ORC_BQ_COSINE: { /* binary_quantized_cosine.rs:40-42,61-63 */
+      float n = sqrtf(bq_dot(vb, vb, vec_bytes(metric, dim)));
+      std::memcpy(out, &n, 4);
+      break;
+    }
+    case ORC_HAMMING: { /* hamming.rs:40-42 idx = 0usize */
+      uint64_t z = 0;
+      std::memcpy(out, &z, 8);
+      break;
+    }
+    default: { /* bias = 0.0 (euclidean.rs:38-40 etc.) */
+      float z = 0.0f;
+      std::memcpy(out, &z, 4);
+    }
+  }
+}
+
+float orc_distance(int32_t metric, int32_t order, uint32_t dim, const void *pv, const void *ph,
+                   const void *qv, const void *qh) {
+  Dist d{metric, order, dim, vec_bytes(metric, dim)};
+  return d(pv, ph, qv, qh);
+}
+float orc_dot(int32_t order, uint32_t dim, const float *a, const float *b) {
+  return order == ORC_ORDER_X86 ? dot_x86(a, b, dim) : wave_reduce(WOP_DOT, a, b, dim);
+}
+float orc_sqeuclid(int32_t order, uint32_t dim, const float *a, const float *b) {
+  return order == ORC_ORDER_X86 ? euclid_x86(a, b, dim) : wave_reduce(WOP_EUCLID, a, b, dim);
+}
+float orc_dot_x86_emulated(uint32_t dim, const float *a, const float *b) {
+  if (dim >= 32) return dot_avx_emul(a, b, dim);
+  if (dim >= 16) return dot_sse_emul(a, b, dim);
+  return dot_scalar(a, b, dim);
+}
+float orc_sqeuclid_x86_emulated(uint32_t dim, const float *a, const float *b) {
+  if (dim >= 32) return euclid_avx_emul(a, b, dim);
+  if (dim >= 16) return euclid_sse_emul(a, b, dim);
+  return euclid_scalar(a, b, dim);
+}
+
+/* hnsw.rs:94-110 get_default_probas */
+uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap) {
+  float level_factor = 1.0f / logf((float)M + 1.1920929e-07f);
+  uint32_t level = 0;
+  for (;;) {
+    float proba = expf((float)level * (-1.0f / level_factor)) * (1.0f - expf(-1.0f / level_factor));
+    if (proba < 1e-09f) break;
+    if (level < cap) out[level] = proba;
+    level++;
+  }
+  return level;
+}
+
+int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
+  if (!opts || !items || !out) return -1;
+  if (opts->M == 0 || opts->M0 < opts->M) return -2;
+  Builder B;
+  B.o = *opts;
+  B.it = *items;
+  B.dist = Dist{opts->metric, opts->order, opts->dim, vec_bytes(opts->metric, opts->dim)};
+  B.n = (uint32_t)items->n;
+  B.threaded = opts->threads > 1;
+  uint32_t n = B.n;
+  auto g = std::make_unique<orc_graph>();
+
+  /* hnsw.rs:141-149 levels (injected) */
+  B.level.assign(items->levels, items->levels + n);
+  uint32_t cur_max = 0;
+  for (uint32_t s = 0; s < n; s++) cur_max = std::max<uint32_t>(cur_max, B.level[s]);
+
+  /* hnsw.rs:268 sort by level desc. The reference's sort is unstable; ties are taken in
+   * ascending id order here (= the order KAT-1 implies for small inputs). */
+  std::vector<uint32_t> order(n);
+  for (uint32_t s = 0; s < n; s++) order[s] = s;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](uint32_t a, uint32_t b) { return B.level[a] > B.level[b]; });
+
+  if (n > 0) {
+    B.max_level = cur_max; /* :272-276 fresh DB: max_level starts at 0 */
+    /* layers: one map per level 0..=max_level (:279-281) */
+    B.idx.resize(B.max_level + 1);
+    B.lists.resize(B.max_level + 1);
+    B.owner.resize(B.max_level + 1);
+    for (uint32_t l = 0; l <= B.max_level; l++) {
+      B.idx[l].assign(n, -1);
+      uint32_t cnt = 0;
+      for (uint32_t s = 0; s < n; s++)
+        if (B.level[s] >= l) {
+          B.idx[l][s] = (int32_t)cnt++;
+          B.owner[l].push_back(s);
+        }
+      B.lists[l] = std::unique_ptr<NodeList[]>(new NodeList[cnt]);
+    }
+    /* :278-287 every item at max_level is an entry point, pre-registered in all layers */
+    for (uint32_t s = 0; s < n; s++)
+      if (B.level[s] == B.max_level) {
+        B.entry_points.push_back(s);
+        register_item(B, s, B.max_level);
+      }
+  }
+
+  uint64_t evals = 0, links = 0;
+  size_t pos = 0;
+  uint64_t n_done = 0;
+  int nthreads = std::max(1, opts->threads);
+  std::vector<Scratch> scratch(nthreads);
+
+  while (pos < n) {
+    /* hnsw.rs:160 chunk_by level */
+    size_t gend = pos;
+    while (gend < n && B.level[order[gend]] == B.level[order[pos]]) gend++;
+
+    if (opts->batch_max == 0) {
+      if (nthreads == 1) {
+        Scratch &S = scratch[0];
+        for (size_t i = pos; i < gend; i++) {
+          uint32_t q = order[i], lvl = B.level[q];
+          Selection sel;
+          /* NB: registration precedes the walks in the reference (:309), harmless here */
+          insert_search(B, S, q, lvl, sel);
+          register_item(B, q, lvl);
+          insert_apply(B, q, lvl, sel, S.evals, links);
+        }
+      } else {
+        /* rayon-like: grp.into_par_iter().try_for_each(insert) :172-185 */
+        std::atomic<size_t> next{pos};
+        std::vector<std::thread> th;
+        std::vector<uint64_t> tlinks(nthreads, 0);
+        for (int t = 0; t < nthreads; t++)
+          th.emplace_back([&, t]() {
+            Scratch &S = scratch[t];
+            for (;;) {
+              size_t i = next.fetch_add(1);
+              if (i >= gend) break;
+              uint32_t q = order[i], lvl = B.level[q];
+              /* the reference interleaves walk/prune/link per layer; with concurrent threads the
+               * per-layer interleaving is kept so that lower walks see this item's upper links */
+              std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end());
+              auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
+              std::vector<Link> res, sel;
+              for (uint32_t l = B.max_level; l > lvl; l--) {
+                walk_layer(B, S, qd, eps, l, 1, res);
+                eps.assign(1, res.front().id);
+              }
+              register_item(B, q, lvl);
+              for (int32_t l = (int32_t)lvl; l >= 0; l--) {
+                walk_layer(B, S, qd, eps, (uint32_t)l, B.o.ef_construction, res);
+                robust_prune(B, res, B.cap(lvl), S.evals, sel);
+                eps.clear();
+                for (const Link &s : sel) {
+                  add_link(B, q, s, (uint32_t)l, S.evals);
+                  add_link(B, s.id, Link{s.d, q}, (uint32_t)l, S.evals);
+                  eps.push_back(s.id);
+                  tlinks[t] += 2;
+                }
+              }
+            }
+          });
+        for (auto &t : th) t.join();
+        for (uint64_t v : tlinks) links += v;
+      }
+      n_done += gend - pos;
+      pos = gend;
+    } else {
+      /* batch-synchronous schedule: every member of a batch searches the same frozen graph,
+       * then links are applied in batch order (DESIGN.md "Batch semantics") */
+      size_t bsz = orc_batch_size(opts->batch_frac, opts->batch_max, n_done);
+      size_t bend = std::min(gend, pos + bsz);
+      size_t cnt = bend - pos;
+      std::vector<Selection> sels(cnt);
+      if (nthreads == 1) {
+        for (size_t i = 0; i < cnt; i++)
+          insert_search(B, scratch[0], order[pos + i], B.level[order[pos + i]], sels[i]);
+      } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+          th.emplace_back([&, t]() {
+            for (;;) {
+              size_t i = next.fetch_add(1);
+              if (i >= cnt) break;
+              insert_search(B, scratch[t], order[pos + i], B.level[order[pos + i]], sels[i]);
+            }
+          });
+        for (auto &t : th) t.join();
+      }
+      bool was_threaded = B.threaded;
+      B.threaded = false; /* apply is sequential by definition */
+      for (size_t i = 0; i < cnt; i++) register_item(B, order[pos + i], B.level[order[pos + i]]);
+      for (size_t i = 0; i < cnt; i++)
+        insert_apply(B, order[pos + i], B.level[order[pos + i]], sels[i], evals, links);
+      B.threaded = was_threaded;
+      n_done += cnt;
+      pos = bend;
+    }
+  }
+  for (auto &s : scratch) evals += s.evals;
+
+  /* hnsw.rs:191-213 write loop, emitted sorted by (item, layer) = LMDB key order (key.rs:54-66) */
+  g->max_level = B.max_level;
+  for (uint32_t s : B.entry_points) g->entry_points.push_back(items->ids[s]);
+  g->offsets.push_back(0);
+  g->raw_offsets.push_back(0);
+  std::vector<uint32_t> tmp;
+  for (uint32_t s = 0; s < n; s++)
+    for (uint32_t l = 0; l < B.idx.size(); l++) {
+      NodeList *nl = B.list(l, s);
+      if (!nl || !nl->present.load()) continue;
+      g->rec_item.push_back(items->ids[s]);
+      g->rec_layer.push_back((uint8_t)l);
+      tmp.clear();
+      for (const Link &k : nl->links) {
+        tmp.push_back(items->ids[k.id]);
+        g->raw_nbrs.push_back(items->ids[k.id]);
+        g->raw_dists.push_back(k.d);
+      }
+      g->raw_offsets.push_back(g->raw_nbrs.size());
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end()); /* RoaringBitmap::from_iter */
+      g->nbrs.insert(g->nbrs.end(), tmp.begin(), tmp.end());
+      g->offsets.push_back(g->nbrs.size());
+    }
+  g->n_evals = evals;
+  g->n_links = links;
+  *out = g.release();
+  return 0;
+}
+
+void orc_graph_free(orc_graph *g) { delete g; }
+uint64_t orc_graph_n_records(const orc_graph *g) { return g->rec_item.size(); }
+uint64_t orc_graph_n_links(const orc_graph *g) { return g->nbrs.size(); }
+void orc_graph_export(const orc_graph *g, uint32_t *rec_item, uint8_t *rec_layer, uint64_t *offsets,
+                      uint32_t *nbrs) {
+  std::memcpy(rec_item, g->rec_item.data(), g->rec_item.size() * 4);
+  std::memcpy(rec_layer, g->rec_layer.data(), g->rec_layer.size());
+  std::memcpy(offsets, g->offsets.data(), g->offsets.size() * 8);
+  if (!g->nbrs.empty()) std::memcpy(nbrs, g->nbrs.data(), g->nbrs.size() * 4);
+}
+uint64_t orc_graph_n_raw(const orc_graph *g) { return g->raw_nbrs.size(); }
+void orc_graph_export_raw(const orc_graph *g, uint64_t *offsets, uint32_t *nbrs, float *dists) {
+  std::memcpy(offsets, g->raw_offsets.data(), g->raw_offsets.size() * 8);
+  if (!g->raw_nbrs.empty()) {
+    std::memcpy(nbrs, g->raw_nbrs.data(), g->raw_nbrs.size() * 4);
+    std::memcpy(dists, g->raw_dists.data(), g->raw_dists.size() * 4);
+  }
+}
+uint32_t orc_graph_entry_points(const orc_graph *g, uint32_t *out, uint32_t cap) {
+  for (uint32_t i = 0; i < g->entry_points.size() && i < cap; i++) out[i] = g->entry_points[i];
+  return (uint32_t)g->entry_points.size();
+}
+uint32_t orc_graph_max_level(const orc_graph *g) { return g->max_level; }
+uint64_t orc_graph_distance_evals(const orc_graph *g) { return g->n_evals; }
+uint64_t orc_graph_links_added(const orc_graph *g) { return g->n_links; }
+
+/* ------------------------------------------------------------------ */
+/* Reader::nns().by_vector — reader.rs:301-369 (visit), 722-800 (hnsw_search) */
+/* ------------------------------------------------------------------ */
+int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *items,
+               uint64_t n_records, const uint32_t *rec_item, const uint8_t *rec_layer,
+               const uint64_t *offsets, const uint32_t *nbrs, const uint32_t *entry_points,
+               uint32_t n_entry_points, uint32_t max_level, uint64_t n_queries, const void *qvecs,
+               size_t qstride, const void *qhdrs, uint32_t k, uint32_t ef_search, int32_t threads,
+               uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+  uint32_t n = (uint32_t)items->n;
+  Dist dist{metric, order, dim, vec_bytes(metric, dim)};
+  size_t hsz = items->header_size;
+  /* id -> slot (ids ascending) */
+  auto slot_of = [&](uint32_t id) -> int64_t {
+    const uint32_t *b = items->ids, *e = items->ids + n;
+    const uint32_t *p = std::lower_bound(b, e, id);
+    return (p != e && *p == id) ? (int64_t)(p - b) : -1;
+  };
+  /* per layer: slot -> record index */
+  std::vector<std::vector<int64_t>> rec_of(max_level + 1, std::vector<int64_t>(n, -1));
+  for (uint64_t r = 0; r < n_records; r++) {
+    int64_t s = slot_of(rec_item[r]);
+    if (s < 0 || rec_layer[r] > max_level) continue;
+    rec_of[rec_layer[r]][s] = (int64_t)r;
+  }
+  std::vector<uint32_t> ep_slots;
+  for (uint32_t i = 0; i < n_entry_points; i++) {
+    int64_t s = slot_of(entry_points[i]);
+    if (s < 0) return -3;
+    ep_slots.push_back((uint32_t)s);
+  }
+  std::atomic<int> err{0};
+  auto run_query = [&](uint64_t qi, Scratch &path) {
+    const uint8_t *qv = (const uint8_t *)qvecs + qi * qstride;
+    const uint8_t *qh = (const uint8_t *)qhdrs + qi * hsz;
+    out_counts[qi] = 0;
+    if (n == 0) return; /* reader.rs:652-654 */
+    uint64_t dummy = 0;
+    auto qd = [&](uint32_t s) {
+      dummy++;
+      return dist(qv, qh, (const uint8_t *)items->vectors + (size_t)s * items->stride,
+                  (const uint8_t *)items->headers + (size_t)s * hsz);
+    };
+    std::vector<Link> res;
+    /* Visitor::visit, reader.rs:301-369 (no candidate filter, no cancel) */
+    auto visit = [&](const std::vector<uint32_t> &eps, uint32_t level, size_t ef) {
+      std::priority_queue<Link, std::vector<Link>, CandLess> sq;
+      res.clear();
+      auto res_insert = [&](const Link &l) {
+        uint64_t key = link_key(l);
+        auto pos = std::lower_bound(res.begin(), res.end(), key,
+                                    [](const Link &a, uint64_t kk) { return link_key(a) < kk; });
+        res.insert(pos, l);
+      };
+      for (uint32_t ep : eps) {
+        Link l{qd(ep), ep};
+        sq.push(l);
+        path.visit(ep);
+        res_insert(l);
+      }
+      while (!sq.empty()) {
+        float f = sq.top().d;
+        float f_max = res.empty() ? 3.4028235e38f : res.back().d; /* unwrap_or(f32::MAX) :337 */
+        if (f > f_max) break;
+        uint32_t c = sq.top().id;
+        sq.pop();
+        int64_t r = rec_of[level][c];
+        if (r < 0) { /* .expect("Links must exist") :343-344 */
+          err.store(-4);
+          return;
+        }
+        for (uint64_t j = offsets[r]; j < offsets[r + 1]; j++) {
+          int64_t ps = slot_of(nbrs[j]);
+          if (ps < 0) {
+            err.store(-5);
+            return;
+          }
+          uint32_t p = (uint32_t)ps;
+          if (!path.visit(p)) continue;
+          float d = qd(p);
+          if (res.size() < ef || d < f_max) {
+            Link l{d, p};
+            sq.push(l);
+            if (res.size() == ef) {
+              res_insert(l);
+              res.pop_back();
+            } else {
+              res_insert(l);
+            }
+          }
+        }
+      }
+    };
+    path.begin(n);
+    std::vector<uint32_t> eps = ep_slots;
+    /* reader.rs:732-741: the path bitmap is shared across the greedy layers */
+    for (uint32_t l = max_level; l >= 1; l--) {
+      visit(eps, l, 1);
+      if (err.load()) return;
+      eps.assign(1, res.front().id);
+    }
+    path.begin(n); /* path.clear() :743 */
+    size_t ef = std::max<size_t>(ef_search, k); /* :746 */
+    visit(eps, 0, ef);
+    if (err.load()) return;
+    std::vector<Link> neighbours = res;
+    if (neighbours.size() < k) { /* exhaustive fallback :771-795 */
+      for (uint32_t s = 0; s < n; s++) {
+        if (path.stamp[s] == path.epoch) continue;
+        size_t ef2 = ef_search > neighbours.size() ? ef_search - neighbours.size() : 0;
+        visit(std::vector<uint32_t>{s}, 0, ef2);
+        if (err.load()) return;
+        for (const Link &l : res) neighbours.push_back(l);
+        if (neighbours.size() >= ef_search) break;
+      }
+      std::sort(neighbours.begin(), neighbours.end(),
+                [](const Link &a, const Link &b) { return link_key(a) < link_key(b); });
+    }
+    uint32_t cnt = (uint32_t)std::min<size_t>(k, neighbours.size()); /* drain_asc().take(k) :797 */
+    for (uint32_t i = 0; i < cnt; i++) {
+      out_ids[qi * k + i] = items->ids[neighbours[i].id];
+      out_dists[qi * k + i] = neighbours[i].d;
+    }
+    out_counts[qi] = cnt;
+  };
+  int nt = std::max(1, threads);
+  std::atomic<uint64_t> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&]() {
+      Scratch path;
+      for (;;) {
+        uint64_t qi = next.fetch_add(1);
+        if (qi >= n_queries || err.load()) break;
+        run_query(qi, path);
+      }
+    });
+  for (auto &t : th) t.join();
+  return err.load();
+}
+
+/* ------------------------------------------------------------------ */
+/* on-disk records                                                     */
+/* ------------------------------------------------------------------ */
+/* key.rs:57-66: index u16 BE | mode u8 | item u32 BE | layer u8 */
+void orc_encode_key(uint16_t index, uint8_t mode, uint32_t item, uint8_t layer, uint8_t out[8]) {
+  out[0] = (uint8_t)(index >> 8);
+  out[1] = (uint8_t)index;
+  out[2] = mode;
+  out[3] = (uint8_t)(item >> 24);
+  out[4] = (uint8_t)(item >> 16);
+  out[5] = (uint8_t)(item >> 8);
+  out[6] = (uint8_t)item;
+  out[7] = layer;
+}
+
+/* [3P] roaring 0.10.9 RoaringBitmap::serialize_into — portable RoaringFormatSpec,
+ * SERIAL_COOKIE_NO_RUNCONTAINER (12346), array containers for cardinality <= 4096 else 8 KiB
+ * bitmap containers, offset header always present. */
+size_t orc_roaring_serialize(const uint32_t *ids, uint64_t n, uint8_t *out) {
+  struct C {
+    uint16_t key;
+    uint64_t begin, end;
+  };
+  std::vector<C> cs;
+  for (uint64_t i = 0; i < n;) {
+    uint16_t key = (uint16_t)(ids[i] >> 16);
+    uint64_t j = i;
+    while (j < n && (uint16_t)(ids[j] >> 16) == key) j++;
+    cs.push_back({key, i, j});
+    i = j;
+  }
+  size_t size = 8 + 8 * cs.size();
+  for (auto &c : cs) size += (c.end - c.begin) <= 4096 ? 2 * (c.end - c.begin) : 8192;
+  if (!out) return size;
+  auto w16 = [&](size_t &p, uint16_t v) {
+    out[p++] = (uint8_t)v;
+    out[p++] = (uint8_t)(v >> 8);
+  };
+  auto w32 = [&](size_t &p, uint32_t v) {
+    for (int k = 0; k < 4; k++) out[p++] = (uint8_t)(v >> (8 * k));
+  };
+  size_t p = 0;
+  w32(p, 12346u);
+  w32(p, (uint32_t)cs.size());
+  for (auto &c : cs) {
+    w16(p, c.key);
+    w16(p, (uint16_t)(c.end - c.begin - 1));
+  }
+  uint32_t off = (uint32_t)(8 + 8 * cs.size());
+  for (auto &c : cs) {
+    w32(p, off);
+    off += (c.end - c.begin) <= 4096 ? (uint32_t)(2 * (c.end - c.begin)) : 8192u;
+  }
+  for (auto &c : cs) {
+    if (c.end - c.begin <= 4096) {
+      for (uint64_t i = c.begin; i < c.end; i++) w16(p, (uint16_t)ids[i]);
+    } else {
+      std::memset(out + p, 0, 8192);
+      for (uint64_t i = c.begin; i < c.end; i++) {
+        uint16_t lo = (uint16_t)ids[i];
+        out[p + (lo >> 3)] |= (uint8_t)(1u << (lo & 7)); /* u64 LE words == little-endian bit array */
+      }
+      p += 8192;
+    }
+  }
+  return size;
+}
+
+static const char *metric_name(int metric) {
+  switch (metric) { /* cosine.rs:32-34 etc. */
+    case ORC_COSINE: return "cosine";
+    case ORC_EUCLIDEAN: return "euclidean";
+    case ORC_MANHATTAN: return "manhattan";
+    case ORC_HAMMING: return "hamming";
+    case ORC_BQ_COSINE: return "binary quantized cosine";
+    case ORC_BQ_EUCLIDEAN: return "binary quantized euclidean";
+    case ORC_BQ_MANHATTAN: return "binary quantized manhattan";
+  }
+  return "";
+}
+
+size_t orc_encode_kv(const orc_graph *g, const orc_opts *opts, const orc_items *items,
+                     uint16_t index, int with_items, uint8_t *out, size_t cap) {
+  std::vector<uint8_t> buf;
+  auto put = [&](const uint8_t key[8], const std::vector<uint8_t> &val) {
+    uint32_t kl = 8, vl = (uint32_t)val.size();
+    for (int k = 0; k < 4; k++) buf.push_back((uint8_t)(kl >> (8 * k)));
+    buf.insert(buf.end(), key, key + 8);
+    for (int k = 0; k < 4; k++) buf.push_back((uint8_t)(vl >> (8 * k)));
+    buf.insert(buf.end(), val.begin(), val.end());
+  };
+  uint8_t key[8];
+  std::vector<uint8_t> val;
+  /* Metadata (metadata.rs:28-48): name \0 | dims u32 BE | roaring size u32 BE | roaring(items) |
+   * entry points (native-endian u32 each, node.rs ItemIds::raw_bytes) | max_level u8 */
+  {
+    val.clear();
+    const char *nm = metric_name(opts->metric);
+    val.insert(val.end(), nm, nm + std::strlen(nm));
+    val.push_back(0);
+    uint32_t dims = opts->dim;
+    for (int k = 3; k >= 0; k--) val.push_back((uint8_t)(dims >> (8 * k)));
+    size_t rs = orc_roaring_serialize(items->ids, items->n, nullptr);
+    for (int k = 3; k >= 0; k--) val.push_back((uint8_t)((uint32_t)rs >> (8 * k)));
+    size_t at = val.size();
+    val.resize(at + rs);
+    orc_roaring_serialize(items->ids, items->n, val.data() + at);
+    for (uint32_t ep : g->entry_points) {
+      uint8_t b[4];
+      std::memcpy(b, &ep, 4);
+      val.insert(val.end(), b, b + 4);
+    }
+    val.push_back((uint8_t)g->max_level);
+    orc_encode_key(index, 0, 0, 0, key);
+    put(key, val);
+  }
+  /* Version (version.rs:36-48): 3 x u32 BE = 0.1.3 (Cargo.toml version) */
+  {
+    val.clear();
+    uint32_t v[3] = {0, 1, 3};
+    for (uint32_t x : v)
+      for (int k = 3; k >= 0; k--) val.push_back((uint8_t)(x >> (8 * k)));
+    orc_encode_key(index, 0, 1, 0, key);
+    put(key, val);
+  }
+  /* Links (node.rs:141-144): 0x01 | roaring */
+  for (uint64_t r = 0; r < g->rec_item.size(); r++) {
+    uint64_t b = g->offsets[r], e = g->offsets[r + 1];
+    size_t rs = orc_roaring_serialize(g->nbrs.data() + b, e - b, nullptr);
+    val.assign(1 + rs, 0);
+    val[0] = 1;
+    orc_roaring_serialize(g->nbrs.data() + b, e - b, val.data() + 1);
+    orc_encode_key(index, 2, g->rec_item[r], g->rec_layer[r], key);
+    put(key, val);
+  }
+  /* Items (node.rs:136-140): 0x00 | header | vector bytes */
+  if (with_items) {
+    size_t vb = vec_bytes(opts->metric, opts->dim), hb = items->header_size;
+    for (uint64_t s = 0; s < items->n; s++) {
+      val.assign(1 + hb + vb, 0);
+      std::memcpy(val.data() + 1, (const uint8_t *)items->headers + s * hb, hb);
+      std::memcpy(val.data() + 1 + hb, (const uint8_t *)items->vectors + s * items->stride, vb);
+      orc_encode_key(index, 3, items->ids[s], 0, key);
+      put(key, val);
+    }
+  }
+  if (out && cap >= buf.size()) std::memcpy(out, buf.data(), buf.size());
+  return buf.size();
+}
+
+} /* extern "C" */

@@ -1,0 +1,141 @@
+/*
+ * hannoy_oracle.h — CPU restatement of hannoy's HNSW build hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under hannoy_amd/ (the product) may
+ * include, link, dlopen or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / the
+ * reported CPU baseline.
+ *
+ * Parity pinning: the real reference (Rust, heed/LMDB) cannot be compiled in
+ * this image (no cargo/rustc, no LMDB).  The restatement is pinned against the
+ * reference's own golden expectations (tests/golden/kat_*.json, derived from
+ * /root/reference/src/tests/writer.rs snapshots and the quantiser tests).
+ * Third-party pieces with **parity unpinned** (no golden bytes in the
+ * reference): rand 0.8.5 ChaCha12/WeightedIndex level sequence (levels are an
+ * input here), roaring 0.10.9 serialisation (public RoaringFormatSpec
+ * followed), heed/LMDB file format (not produced).
+ *
+ * All file:line citations are relative to /root/reference/.
+ */
+#ifndef HANNOY_ORACLE_H
+#define HANNOY_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/distance/mod.rs:3-10 — the seven metrics */
+enum {
+  ORC_COSINE = 0,
+  ORC_EUCLIDEAN = 1,
+  ORC_MANHATTAN = 2,
+  ORC_HAMMING = 3,
+  ORC_BQ_COSINE = 4,
+  ORC_BQ_EUCLIDEAN = 5,
+  ORC_BQ_MANHATTAN = 6
+};
+
+/* f32 summation orders.
+ * ORC_ORDER_X86: what the reference computes on an x86_64 host with AVX+FMA
+ *   (src/spaces/simple.rs:19-47,53-79 dispatch; simple_avx.rs; simple_sse.rs;
+ *   scalar for dim < 16).
+ * ORC_ORDER_WAVE: the wave64 order of the HIP kernels' fast path (per-lane
+ *   float4 fma chains + xor butterfly), see DESIGN.md "Distance orders". */
+enum { ORC_ORDER_X86 = 0, ORC_ORDER_WAVE = 1 };
+
+typedef struct {
+  int32_t metric;
+  uint32_t dim;          /* user dimensions */
+  uint32_t M, M0;        /* const generics of build::<M,M0> (writer.rs:215) */
+  uint32_t ef_construction; /* writer.rs:49 default 100 */
+  float alpha;           /* writer.rs:51 default 1.0 */
+  int32_t order;         /* ORC_ORDER_* */
+  int32_t threads;       /* 1 = deterministic single thread (tests/mod.rs:105); >1 rayon-like */
+  /* batch-synchronous schedule (the GPU build's semantics); batch_max == 0
+   * means plain sequential insertion (the reference with one thread). */
+  double batch_frac;
+  uint32_t batch_max;
+} orc_opts;
+
+typedef struct {
+  uint64_t n;
+  const uint32_t *ids;     /* ascending (RoaringBitmap iteration order, hnsw.rs:142-144) */
+  const void *vectors;     /* codec bytes as stored after the header (node.rs:136-140) */
+  size_t stride;           /* bytes between consecutive vectors */
+  const void *headers;     /* header bytes (4 B norm|bias, 8 B for Hamming) */
+  size_t header_size;
+  const uint8_t *levels;   /* level per item (injected; hnsw.rs:113-119 draws them) */
+} orc_items;
+
+typedef struct orc_graph orc_graph;
+
+/* ---- codecs (src/unaligned_vector/) ---- */
+size_t orc_vector_bytes(int32_t metric, uint32_t dim);
+size_t orc_header_bytes(int32_t metric);
+/* Binary::from_slice (binary.rs:80-94) / BinaryQuantized::from_slice (binary_quantized.rs:80-91)
+ * / f32 (f32.rs) depending on metric; writes orc_vector_bytes() bytes. */
+void orc_encode_vector(int32_t metric, uint32_t dim, const float *v, void *out);
+/* D::new_header (cosine.rs:36-38 etc.); always computed in the X86 order. */
+void orc_make_header(int32_t metric, uint32_t dim, const void *vec_bytes, void *out_hdr);
+
+/* ---- distances (src/distance/, all files) ---- */
+float orc_distance(int32_t metric, int32_t order, uint32_t dim, const void *pv, const void *ph,
+                   const void *qv, const void *qh);
+float orc_dot(int32_t order, uint32_t dim, const float *a, const float *b);
+float orc_sqeuclid(int32_t order, uint32_t dim, const float *a, const float *b);
+/* scalar emulation of the AVX/SSE kernels (always available), for self-checks
+ * against the intrinsic versions used when compiled with -mavx2 -mfma */
+float orc_dot_x86_emulated(uint32_t dim, const float *a, const float *b);
+float orc_sqeuclid_x86_emulated(uint32_t dim, const float *a, const float *b);
+
+/* ---- level assignment (hnsw.rs:94-119) ---- */
+/* get_default_probas: returns count, writes up to cap probabilities */
+uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap);
+
+/* ---- build (hnsw.rs:122-216, fresh DB) ---- */
+int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out);
+void orc_graph_free(orc_graph *g);
+uint64_t orc_graph_n_records(const orc_graph *g);
+uint64_t orc_graph_n_links(const orc_graph *g); /* total ids over all records (deduplicated) */
+/* records sorted by (item id, layer); offsets has n_records+1 entries; neighbours are item ids
+ * ascending & deduplicated (RoaringBitmap::from_iter, hnsw.rs:204-208) */
+void orc_graph_export(const orc_graph *g, uint32_t *rec_item, uint8_t *rec_layer, uint64_t *offsets,
+                      uint32_t *nbrs);
+/* raw in-memory lists, insertion order with duplicates and distances (NodeState, hnsw.rs:33-35) */
+uint64_t orc_graph_n_raw(const orc_graph *g);
+void orc_graph_export_raw(const orc_graph *g, uint64_t *offsets, uint32_t *nbrs, float *dists);
+uint32_t orc_graph_entry_points(const orc_graph *g, uint32_t *out, uint32_t cap);
+uint32_t orc_graph_max_level(const orc_graph *g);
+uint64_t orc_graph_distance_evals(const orc_graph *g);
+uint64_t orc_graph_links_added(const orc_graph *g);
+
+/* ---- search: Reader::nns().by_vector (reader.rs:301-369, 642-665, 722-800) ---- */
+/* graph given as exported records; queries are codec bytes + header. Returns
+ * number of hits written per query in out_counts (<= k). */
+int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *items,
+               uint64_t n_records, const uint32_t *rec_item, const uint8_t *rec_layer,
+               const uint64_t *offsets, const uint32_t *nbrs, const uint32_t *entry_points,
+               uint32_t n_entry_points, uint32_t max_level, uint64_t n_queries, const void *qvecs,
+               size_t qstride, const void *qhdrs, uint32_t k, uint32_t ef_search, int32_t threads,
+               uint32_t *out_ids, float *out_dists, uint32_t *out_counts);
+
+/* ---- on-disk records (key.rs:54-82, node.rs:130-174, metadata.rs:22-73, version.rs:33-60) ---- */
+void orc_encode_key(uint16_t index, uint8_t mode, uint32_t item, uint8_t layer, uint8_t out[8]);
+/* RoaringBitmap::serialize_into of ascending ids; returns bytes written (or needed if out==NULL) */
+size_t orc_roaring_serialize(const uint32_t *ids, uint64_t n, uint8_t *out);
+/* full KV stream the build writes (Links + Metadata + Version, optional Items), LMDB key order.
+ * Output framing: repeated [u32 LE klen][key][u32 LE vlen][value]. Returns total bytes (needed
+ * size if out == NULL or cap too small). */
+size_t orc_encode_kv(const orc_graph *g, const orc_opts *opts, const orc_items *items,
+                     uint16_t index, int with_items, uint8_t *out, size_t cap);
+
+/* schedule shared definition: batch size for n_done already-inserted items */
+uint32_t orc_batch_size(double frac, uint32_t bmax, uint64_t n_done);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

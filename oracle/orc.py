@@ -1,0 +1,313 @@
+"""ctypes binding of the CPU oracle (oracle/libhannoy_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by hannoy_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libhannoy_oracle.so")
+
+COSINE, EUCLIDEAN, MANHATTAN, HAMMING, BQ_COSINE, BQ_EUCLIDEAN, BQ_MANHATTAN = range(7)
+ORDER_X86, ORDER_WAVE = 0, 1
+
+
+def build_lib(force=False):
+    src = os.path.join(HERE, "hannoy_oracle.cpp")
+    hdr = os.path.join(HERE, "hannoy_oracle.h")
+    if (force or not os.path.exists(LIB)
+            or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", HERE, "-B"], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+class Opts(C.Structure):
+    _fields_ = [("metric", C.c_int32), ("dim", C.c_uint32), ("M", C.c_uint32), ("M0", C.c_uint32),
+                ("ef_construction", C.c_uint32), ("alpha", C.c_float), ("order", C.c_int32),
+                ("threads", C.c_int32), ("batch_frac", C.c_double), ("batch_max", C.c_uint32)]
+
+
+class Items(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("ids", C.c_void_p), ("vectors", C.c_void_p),
+                ("stride", C.c_size_t), ("headers", C.c_void_p), ("header_size", C.c_size_t),
+                ("levels", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_lib()
+        L = C.CDLL(LIB)
+        L.orc_vector_bytes.restype = C.c_size_t
+        L.orc_vector_bytes.argtypes = [C.c_int32, C.c_uint32]
+        L.orc_header_bytes.restype = C.c_size_t
+        L.orc_header_bytes.argtypes = [C.c_int32]
+        L.orc_encode_vector.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_make_header.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_distance.restype = C.c_float
+        L.orc_distance.argtypes = [C.c_int32, C.c_int32, C.c_uint32] + [C.c_void_p] * 4
+        for f in (L.orc_dot, L.orc_sqeuclid):
+            f.restype = C.c_float
+            f.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+        for f in (L.orc_dot_x86_emulated, L.orc_sqeuclid_x86_emulated):
+            f.restype = C.c_float
+            f.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_level_probas.restype = C.c_uint32
+        L.orc_level_probas.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_build.restype = C.c_int
+        L.orc_build.argtypes = [C.POINTER(Opts), C.POINTER(Items), C.POINTER(C.c_void_p)]
+        L.orc_graph_free.argtypes = [C.c_void_p]
+        for name in ("orc_graph_n_records", "orc_graph_n_links", "orc_graph_n_raw",
+                     "orc_graph_distance_evals", "orc_graph_links_added"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_graph_export.argtypes = [C.c_void_p] * 5
+        L.orc_graph_export_raw.argtypes = [C.c_void_p] * 4
+        L.orc_graph_entry_points.restype = C.c_uint32
+        L.orc_graph_entry_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_graph_max_level.restype = C.c_uint32
+        L.orc_graph_max_level.argtypes = [C.c_void_p]
+        L.orc_search.restype = C.c_int
+        L.orc_search.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.POINTER(Items), C.c_uint64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
+                                 C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]
+        L.orc_encode_key.argtypes = [C.c_uint16, C.c_uint8, C.c_uint32, C.c_uint8, C.c_void_p]
+        L.orc_roaring_serialize.restype = C.c_size_t
+        L.orc_roaring_serialize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_encode_kv.restype = C.c_size_t
+        L.orc_encode_kv.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(Items), C.c_uint16,
+                                    C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_batch_size.restype = C.c_uint32
+        L.orc_batch_size.argtypes = [C.c_double, C.c_uint32, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def vector_bytes(metric, dim):
+    return lib().orc_vector_bytes(metric, dim)
+
+
+def header_bytes(metric):
+    return lib().orc_header_bytes(metric)
+
+
+def encode_vectors(metric, vecs):
+    """f32 [n, dim] -> codec bytes uint8 [n, vector_bytes]."""
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    n, dim = vecs.shape
+    vb = vector_bytes(metric, dim)
+    out = np.zeros((n, vb), dtype=np.uint8)
+    L = lib()
+    for i in range(n):
+        L.orc_encode_vector(metric, dim, _p(vecs[i]), _p(out[i]))
+    return out
+
+
+def make_headers(metric, dim, codes):
+    n = codes.shape[0]
+    hb = header_bytes(metric)
+    out = np.zeros((n, hb), dtype=np.uint8)
+    L = lib()
+    for i in range(n):
+        L.orc_make_header(metric, dim, _p(codes[i]), _p(out[i]))
+    return out
+
+
+def distance(metric, order, dim, pv, ph, qv, qh):
+    return float(lib().orc_distance(metric, order, dim, _p(pv), _p(ph), _p(qv), _p(qh)))
+
+
+def dot(order, a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return np.float32(lib().orc_dot(order, a.size, _p(a), _p(b)))
+
+
+def sqeuclid(order, a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return np.float32(lib().orc_sqeuclid(order, a.size, _p(a), _p(b)))
+
+
+def dot_emulated(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return np.float32(lib().orc_dot_x86_emulated(a.size, _p(a), _p(b)))
+
+
+def sqeuclid_emulated(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return np.float32(lib().orc_sqeuclid_x86_emulated(a.size, _p(a), _p(b)))
+
+
+def level_probas(M):
+    out = np.zeros(64, dtype=np.float32)
+    n = lib().orc_level_probas(M, _p(out), 64)
+    return out[:n].copy()
+
+
+def batch_size(frac, bmax, n_done):
+    return lib().orc_batch_size(frac, bmax, n_done)
+
+
+class Dataset:
+    """Items as FrozenReader would hand them over (parallel.rs:33-45)."""
+
+    def __init__(self, metric, dim, ids, codes, headers, levels):
+        self.metric, self.dim = metric, dim
+        self.ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert np.all(np.diff(self.ids.astype(np.int64)) > 0), "ids must be ascending"
+        self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.headers = np.ascontiguousarray(headers, dtype=np.uint8)
+        self.levels = np.ascontiguousarray(levels, dtype=np.uint8)
+        self.n = len(self.ids)
+
+    @classmethod
+    def from_f32(cls, metric, vecs, levels, ids=None):
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        n, dim = vecs.shape
+        ids = np.arange(n, dtype=np.uint32) if ids is None else ids
+        codes = encode_vectors(metric, vecs)
+        return cls(metric, dim, ids, codes, make_headers(metric, dim, codes), levels)
+
+    def items_struct(self):
+        return Items(self.n, _p(self.ids).value, _p(self.codes).value, self.codes.shape[1],
+                     _p(self.headers).value, self.headers.shape[1], _p(self.levels).value)
+
+
+class Graph:
+    def __init__(self, handle):
+        L = lib()
+        self._h = handle
+        nrec = L.orc_graph_n_records(handle)
+        nl = L.orc_graph_n_links(handle)
+        self.rec_item = np.zeros(nrec, np.uint32)
+        self.rec_layer = np.zeros(nrec, np.uint8)
+        self.offsets = np.zeros(nrec + 1, np.uint64)
+        self.nbrs = np.zeros(max(nl, 1), np.uint32)
+        L.orc_graph_export(handle, _p(self.rec_item), _p(self.rec_layer), _p(self.offsets),
+                           _p(self.nbrs))
+        self.nbrs = self.nbrs[:nl]
+        nraw = L.orc_graph_n_raw(handle)
+        self.raw_offsets = np.zeros(nrec + 1, np.uint64)
+        self.raw_nbrs = np.zeros(max(nraw, 1), np.uint32)
+        self.raw_dists = np.zeros(max(nraw, 1), np.float32)
+        L.orc_graph_export_raw(handle, _p(self.raw_offsets), _p(self.raw_nbrs), _p(self.raw_dists))
+        self.raw_nbrs, self.raw_dists = self.raw_nbrs[:nraw], self.raw_dists[:nraw]
+        eps = np.zeros(4096, np.uint32)
+        ne = L.orc_graph_entry_points(handle, _p(eps), 4096)
+        self.entry_points = eps[:ne].copy()
+        self.max_level = L.orc_graph_max_level(handle)
+        self.n_distance_evals = L.orc_graph_distance_evals(handle)
+        self.n_links_added = L.orc_graph_links_added(handle)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_graph_free(self._h)
+            self._h = None
+
+    def as_dict(self):
+        """{(item, layer): [neighbour ids]}"""
+        out = {}
+        for r in range(len(self.rec_item)):
+            a, b = int(self.offsets[r]), int(self.offsets[r + 1])
+            out[(int(self.rec_item[r]), int(self.rec_layer[r]))] = self.nbrs[a:b].tolist()
+        return out
+
+    def raw_dict(self):
+        out = {}
+        for r in range(len(self.rec_item)):
+            a, b = int(self.raw_offsets[r]), int(self.raw_offsets[r + 1])
+            out[(int(self.rec_item[r]), int(self.rec_layer[r]))] = (
+                self.raw_nbrs[a:b].tolist(), self.raw_dists[a:b].copy())
+        return out
+
+
+def make_opts(metric, dim, M=16, M0=32, ef=100, alpha=1.0, order=ORDER_X86, threads=1,
+              batch_frac=0.0, batch_max=0):
+    return Opts(metric, dim, M, M0, ef, alpha, order, threads, batch_frac, batch_max)
+
+
+def build(ds, **kw):
+    o = make_opts(ds.metric, ds.dim, **kw)
+    it = ds.items_struct()
+    h = C.c_void_p()
+    rc = lib().orc_build(C.byref(o), C.byref(it), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"orc_build failed: {rc}")
+    g = Graph(h)
+    g.opts = o
+    return g
+
+
+def search(ds, graph, qcodes, qheaders, k=10, ef_search=100, order=ORDER_X86, threads=1):
+    """graph: anything with rec_item/rec_layer/offsets/nbrs/entry_points/max_level arrays."""
+    qcodes = np.ascontiguousarray(qcodes, np.uint8)
+    qheaders = np.ascontiguousarray(qheaders, np.uint8)
+    nq = qcodes.shape[0]
+    ids = np.zeros((nq, k), np.uint32)
+    dists = np.zeros((nq, k), np.float32)
+    counts = np.zeros(nq, np.uint32)
+    it = ds.items_struct()
+    rec_item = np.ascontiguousarray(graph.rec_item, np.uint32)
+    rec_layer = np.ascontiguousarray(graph.rec_layer, np.uint8)
+    offsets = np.ascontiguousarray(graph.offsets, np.uint64)
+    nbrs = np.ascontiguousarray(graph.nbrs, np.uint32)
+    eps = np.ascontiguousarray(graph.entry_points, np.uint32)
+    rc = lib().orc_search(ds.metric, order, ds.dim, C.byref(it), len(rec_item), _p(rec_item),
+                          _p(rec_layer), _p(offsets), _p(nbrs), _p(eps), len(eps),
+                          int(graph.max_level), nq, _p(qcodes), qcodes.shape[1], _p(qheaders), k,
+                          ef_search, threads, _p(ids), _p(dists), _p(counts))
+    if rc != 0:
+        raise RuntimeError(f"orc_search failed: {rc}")
+    return ids, dists, counts
+
+
+def encode_key(index, mode, item, layer):
+    out = np.zeros(8, np.uint8)
+    lib().orc_encode_key(index, mode, item, layer, _p(out))
+    return out.tobytes()
+
+
+def roaring_serialize(ids):
+    ids = np.ascontiguousarray(ids, np.uint32)
+    n = lib().orc_roaring_serialize(_p(ids), len(ids), None)
+    out = np.zeros(n, np.uint8)
+    lib().orc_roaring_serialize(_p(ids), len(ids), _p(out))
+    return out.tobytes()
+
+
+def encode_kv(ds, graph, index=0, with_items=False):
+    it = ds.items_struct()
+    n = lib().orc_encode_kv(graph._h, C.byref(graph.opts), C.byref(it), index, int(with_items),
+                            None, 0)
+    out = np.zeros(n, np.uint8)
+    lib().orc_encode_kv(graph._h, C.byref(graph.opts), C.byref(it), index, int(with_items),
+                        _p(out), n)
+    return parse_kv(out.tobytes())
+
+
+def parse_kv(buf):
+    recs, p = [], 0
+    while p < len(buf):
+        kl = int.from_bytes(buf[p:p + 4], "little")
+        key = buf[p + 4:p + 4 + kl]
+        p += 4 + kl
+        vl = int.from_bytes(buf[p:p + 4], "little")
+        recs.append((key, buf[p + 4:p + 4 + vl]))
+        p += 4 + vl
+    return recs
