@@ -1,0 +1,335 @@
+"""ctypes binding of the C ABI in include/hannoy_amd.h (hannoy_amd/libhannoy_amd.so).
+
+The shared library is the product: there is no Python or CPU fallback.  Importing works without a
+GPU (so that symbol/ABI checks can run anywhere); every computing call needs a gfx950 device and
+raises HannoyError otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhannoy_amd.so")
+
+COSINE, EUCLIDEAN, MANHATTAN, HAMMING, BQ_COSINE, BQ_EUCLIDEAN, BQ_MANHATTAN = range(7)
+METRIC_NAMES = ["cosine", "euclidean", "manhattan", "hamming", "binary quantized cosine",
+                "binary quantized euclidean", "binary quantized manhattan"]
+
+OK, ERR_INVALID_ARG, ERR_CANCELLED, ERR_MISSING_KEY, ERR_INVALID_DIM = 0, -1, -2, -3, -4
+ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_DEVICE, ERR_OOM = -5, -6, -7, -8
+
+EXPORTED = [
+    "hny_build", "hny_graph_free", "hny_builder_create", "hny_builder_reset",
+    "hny_builder_next_batch", "hny_builder_search", "hny_builder_apply", "hny_builder_sync",
+    "hny_builder_finish", "hny_builder_destroy", "hny_batch_size", "hny_builder_distances",
+    "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
+    "hny_encode_kv", "hny_last_error", "hny_version",
+]
+
+
+class HannoyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hannoy_amd error {code}: {msg}")
+        self.code = code
+
+
+class BuildCancelled(HannoyError):
+    """Error::BuildCancelled (/root/reference/src/error.rs:58-59)"""
+
+
+CANCEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
+KV_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8),
+                      C.c_size_t)
+
+
+class BuildOpts(C.Structure):
+    _fields_ = [("metric", C.c_int32), ("dim", C.c_uint32), ("M", C.c_uint32), ("M0", C.c_uint32),
+                ("ef_construction", C.c_uint32), ("alpha", C.c_float), ("seed", C.c_uint64),
+                ("cancel", CANCEL_FN), ("cancel_ctx", C.c_void_p),
+                ("progress", PROGRESS_FN), ("progress_ctx", C.c_void_p),
+                ("batch_frac", C.c_double), ("batch_max", C.c_uint32), ("device", C.c_int32)]
+
+
+class Items(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("ids", C.c_void_p), ("vectors", C.c_void_p),
+                ("stride", C.c_size_t), ("headers", C.c_void_p), ("header_size", C.c_size_t),
+                ("levels", C.c_void_p)]
+
+
+class GraphStruct(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("rec_item", C.POINTER(C.c_uint32)),
+                ("rec_layer", C.POINTER(C.c_uint8)), ("rec_offset", C.POINTER(C.c_uint64)),
+                ("neighbours", C.POINTER(C.c_uint32)), ("entry_points", C.POINTER(C.c_uint32)),
+                ("n_entry_points", C.c_uint32), ("max_level", C.c_uint32),
+                ("n_links_added", C.c_uint64), ("n_distance_evals", C.c_uint64),
+                ("n_evals_walk", C.c_uint64), ("n_evals_prune", C.c_uint64),
+                ("n_evals_apply", C.c_uint64), ("n_batches", C.c_uint64),
+                ("t_upload_s", C.c_double), ("t_build_s", C.c_double), ("t_export_s", C.c_double),
+                ("n_tie_pool_overflow", C.c_uint64)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("first", C.c_uint64), ("count", C.c_uint32), ("level", C.c_uint32),
+                ("n_layers", C.c_uint32), ("sel_stride_u64", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP extension; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m hannoy_amd.build` "
+            "(hipcc --offload-arch=gfx950). hannoy_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.hny_build.restype = C.c_int
+    L.hny_build.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(C.POINTER(GraphStruct))]
+    L.hny_graph_free.argtypes = [C.POINTER(GraphStruct)]
+    L.hny_builder_create.restype = C.c_int
+    L.hny_builder_create.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(vp)]
+    for name in ("hny_builder_reset", "hny_builder_sync"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [vp]
+    L.hny_builder_next_batch.restype = C.c_int
+    L.hny_builder_next_batch.argtypes = [vp, C.POINTER(Batch)]
+    L.hny_builder_search.restype = C.c_int
+    L.hny_builder_search.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.hny_builder_apply.restype = C.c_int
+    L.hny_builder_apply.argtypes = [vp, vp]
+    L.hny_builder_finish.restype = C.c_int
+    L.hny_builder_finish.argtypes = [vp, C.POINTER(C.POINTER(GraphStruct))]
+    L.hny_builder_destroy.argtypes = [vp]
+    L.hny_batch_size.restype = C.c_uint32
+    L.hny_batch_size.argtypes = [C.c_double, C.c_uint32, C.c_uint64]
+    L.hny_builder_distances.restype = C.c_int
+    L.hny_builder_distances.argtypes = [vp, C.c_uint64, vp, vp, vp]
+    L.hny_builder_search_knn.restype = C.c_int
+    L.hny_builder_search_knn.argtypes = [vp, C.c_uint64, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32,
+                                         vp, vp, vp]
+    L.hny_vector_bytes.restype = C.c_size_t
+    L.hny_vector_bytes.argtypes = [C.c_int32, C.c_uint32]
+    L.hny_header_bytes.restype = C.c_size_t
+    L.hny_header_bytes.argtypes = [C.c_int32]
+    L.hny_encode_vectors.restype = C.c_int
+    L.hny_encode_vectors.argtypes = [C.c_int32, C.c_uint32, C.c_uint64, vp, vp, vp]
+    L.hny_encode_kv.restype = C.c_int
+    L.hny_encode_kv.argtypes = [C.POINTER(GraphStruct), C.POINTER(BuildOpts), C.POINTER(Items),
+                                C.c_uint16, C.c_int, KV_SINK, vp]
+    L.hny_last_error.restype = C.c_char_p
+    L.hny_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        msg = load_library().hny_last_error().decode("utf-8", "replace")
+        raise (BuildCancelled if rc == ERR_CANCELLED else HannoyError)(rc, msg)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def vector_bytes(metric, dim):
+    return load_library().hny_vector_bytes(metric, dim)
+
+
+def header_bytes(metric):
+    return load_library().hny_header_bytes(metric)
+
+
+def encode_vectors(metric, vecs):
+    """UnalignedVectorCodec::from_slice + Distance::new_header for a [n, dim] f32 matrix."""
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    n, dim = vecs.shape
+    codes = np.zeros((n, vector_bytes(metric, dim)), np.uint8)
+    headers = np.zeros((n, header_bytes(metric)), np.uint8)
+    _check(load_library().hny_encode_vectors(metric, dim, n, _p(vecs), _p(codes), _p(headers)))
+    return codes, headers
+
+
+class ItemSet:
+    """What FrozenReader hands to the builder (/root/reference/src/parallel.rs:33-45)."""
+
+    def __init__(self, metric, dim, ids, codes, headers, levels=None):
+        self.metric, self.dim = int(metric), int(dim)
+        self.ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.headers = np.ascontiguousarray(headers, dtype=np.uint8)
+        self.levels = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint8)
+        self.n = len(self.ids)
+
+    @classmethod
+    def from_f32(cls, metric, vecs, ids=None, levels=None):
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        codes, headers = encode_vectors(metric, vecs)
+        ids = np.arange(len(vecs), dtype=np.uint32) if ids is None else ids
+        return cls(metric, vecs.shape[1], ids, codes, headers, levels)
+
+    def struct(self):
+        return Items(self.n, _p(self.ids).value, _p(self.codes).value,
+                     self.codes.shape[1] if self.codes.ndim == 2 else 0, _p(self.headers).value,
+                     self.headers.shape[1] if self.headers.ndim == 2 else 0,
+                     None if self.levels is None else _p(self.levels).value)
+
+
+def make_opts(metric, dim, M=16, M0=32, ef_construction=100, alpha=1.0, seed=42, batch_frac=0.0,
+              batch_max=0, device=-1, cancel=None, progress=None):
+    o = BuildOpts()
+    o.metric, o.dim, o.M, o.M0 = metric, dim, M, M0
+    o.ef_construction, o.alpha, o.seed = ef_construction, alpha, seed
+    o.batch_frac, o.batch_max, o.device = batch_frac, batch_max, device
+    keep = []
+    if cancel is not None:
+        fn = CANCEL_FN(lambda _ctx: 1 if cancel() else 0)
+        o.cancel = fn
+        keep.append(fn)
+    if progress is not None:
+        fn = PROGRESS_FN(lambda _ctx, done, total: progress(done, total))
+        o.progress = fn
+        keep.append(fn)
+    o._keep = keep
+    return o
+
+
+class Graph:
+    """Host copy of hny_graph (records the write loop of hnsw.rs:195-213 consumes)."""
+
+    def __init__(self, gp, opts=None, items=None):
+        g = gp.contents
+        nrec = g.n_records
+        self.rec_item = np.ctypeslib.as_array(g.rec_item, (max(nrec, 1),))[:nrec].copy()
+        self.rec_layer = np.ctypeslib.as_array(g.rec_layer, (max(nrec, 1),))[:nrec].copy()
+        self.offsets = np.ctypeslib.as_array(g.rec_offset, (nrec + 1,)).copy()
+        nl = int(self.offsets[-1])
+        self.nbrs = np.ctypeslib.as_array(g.neighbours, (max(nl, 1),))[:nl].copy()
+        ne = g.n_entry_points
+        self.entry_points = np.ctypeslib.as_array(g.entry_points, (max(ne, 1),))[:ne].copy()
+        self.max_level = g.max_level
+        for f in ("n_links_added", "n_distance_evals", "n_evals_walk", "n_evals_prune",
+                  "n_evals_apply", "n_batches", "t_upload_s", "t_build_s", "t_export_s",
+                  "n_tie_pool_overflow"):
+            setattr(self, f, getattr(g, f))
+        self._gp, self._opts, self._items = gp, opts, items
+
+    def __del__(self):
+        if getattr(self, "_gp", None) is not None:
+            load_library().hny_graph_free(self._gp)
+            self._gp = None
+
+    def as_dict(self):
+        return {(int(self.rec_item[r]), int(self.rec_layer[r])):
+                self.nbrs[int(self.offsets[r]):int(self.offsets[r + 1])].tolist()
+                for r in range(len(self.rec_item))}
+
+    def encode_kv(self, index=0, with_items=False):
+        """Byte-exact (key, value) records in LMDB key order (hny_encode_kv)."""
+        out = []
+
+        def sink(_ctx, k, kl, v, vl):
+            out.append((bytes(k[:kl]), bytes(v[:vl])))
+            return 0
+        cb = KV_SINK(sink)
+        it = self._items.struct()
+        _check(load_library().hny_encode_kv(self._gp, C.byref(self._opts), C.byref(it), index,
+                                            int(with_items), cb, None))
+        return out
+
+
+def build(items, **kw):
+    """hny_build: the drop-in for HnswBuilder::build (/root/reference/src/hnsw.rs:122-216)."""
+    o = make_opts(items.metric, items.dim, **kw)
+    it = items.struct()
+    gp = C.POINTER(GraphStruct)()
+    _check(load_library().hny_build(C.byref(o), C.byref(it), C.byref(gp)))
+    return Graph(gp, o, items)
+
+
+class Builder:
+    """Stepwise builder (hny_builder_*): vectors stay resident in HBM across reset()/rebuilds."""
+
+    def __init__(self, items, **kw):
+        self.items = items
+        self.opts = make_opts(items.metric, items.dim, **kw)
+        self._h = C.c_void_p()
+        it = items.struct()
+        _check(load_library().hny_builder_create(C.byref(self.opts), C.byref(it), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load_library().hny_builder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        _check(load_library().hny_builder_reset(self._h))
+
+    def next_batch(self):
+        b = Batch()
+        _check(load_library().hny_builder_next_batch(self._h, C.byref(b)))
+        return b
+
+    def search(self, lo, hi, sel_ptr=None):
+        _check(load_library().hny_builder_search(self._h, lo, hi, sel_ptr))
+
+    def apply(self, sel_ptr=None):
+        _check(load_library().hny_builder_apply(self._h, sel_ptr))
+
+    def sync(self):
+        _check(load_library().hny_builder_sync(self._h))
+
+    def run(self):
+        """All batches on this GPU (what hny_build loops over)."""
+        n = 0
+        while True:
+            b = self.next_batch()
+            if b.count == 0:
+                break
+            self.search(0, b.count)
+            self.apply()
+            n += 1
+        return n
+
+    def finish(self):
+        gp = C.POINTER(GraphStruct)()
+        _check(load_library().hny_builder_finish(self._h, C.byref(gp)))
+        return Graph(gp, self.opts, self.items)
+
+    def distances(self, slot_a, slot_b):
+        a = np.ascontiguousarray(slot_a, np.uint32)
+        b = np.ascontiguousarray(slot_b, np.uint32)
+        out = np.zeros(len(a), np.float32)
+        _check(load_library().hny_builder_distances(self._h, len(a), _p(a), _p(b), _p(out)))
+        return out
+
+    def search_knn(self, qcodes, qheaders, k=10, ef_search=100):
+        """Reader::nns(k).by_vector (/root/reference/src/reader.rs:132-148) on the built graph."""
+        qcodes = np.ascontiguousarray(qcodes, np.uint8)
+        qheaders = np.ascontiguousarray(qheaders, np.uint8)
+        nq = qcodes.shape[0]
+        ids = np.zeros((nq, k), np.uint32)
+        dists = np.zeros((nq, k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        _check(load_library().hny_builder_search_knn(self._h, nq, _p(qcodes), qcodes.shape[1],
+                                                     _p(qheaders), k, ef_search, _p(ids),
+                                                     _p(dists), _p(counts)))
+        return ids, dists, counts

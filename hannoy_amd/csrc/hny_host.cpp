@@ -1,0 +1,983 @@
+// hny_host.cpp — host side of the C ABI in include/hannoy_amd.h: validation, level assignment,
+// HBM residency, the batch-synchronous build driver, export, codecs and on-disk record encoders.
+// Mirrors HnswBuilder::build (/root/reference/src/hnsw.rs:122-216) around the gfx950 kernels in
+// hny_kernels.hip.  No CPU fallback: without a device every computing entry point fails.
+#include "../../include/hannoy_amd.h"
+#include "hny_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(x)                                                                           \
+  do {                                                                                       \
+    hipError_t e_ = (x);                                                                     \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(e_ == hipErrorOutOfMemory ? HNY_ERR_OOM : HNY_ERR_NO_DEVICE, "%s: %s", #x, \
+                  hipGetErrorString(e_));                                                    \
+  } while (0)
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+bool is_binary(int metric) { return metric >= HNY_HAMMING; }
+size_t vec_bytes(int metric, uint32_t dim) {
+  return is_binary(metric) ? (size_t)((dim + 63) / 64) * 8 : (size_t)dim * 4;
+}
+size_t hdr_bytes(int metric) { return metric == HNY_HAMMING ? 8 : 4; }
+uint32_t pow2ceil(uint32_t x) {
+  uint32_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// ---- get_default_probas / get_random_level (hnsw.rs:94-119).  The reference draws from a caller
+// supplied rand::Rng; its ChaCha12 stream is not reproduced (levels can be injected instead). ----
+std::vector<float> level_probas(uint32_t M) {
+  std::vector<float> p;
+  float level_factor = 1.0f / logf((float)M + 1.1920929e-07f);
+  for (uint32_t level = 0;; level++) {
+    float proba = expf((float)level * (-1.0f / level_factor)) * (1.0f - expf(-1.0f / level_factor));
+    if (proba < 1e-09f) break;
+    p.push_back(proba);
+  }
+  return p;
+}
+struct SplitMix64 {
+  uint64_t s;
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+};
+
+// ---- f32 dot in the reference's x86 order, for Distance::new_header (cosine.rs:36-38,58-60):
+// 32 fma partials + hsum tree (simple_avx.rs:8-13,69-110), 16 unfused partials for 16 <= n < 32
+// (simple_sse.rs:64-110), scalar below (simple.rs:81-83) ----
+float hsum8(const float *x) {
+  float a0 = x[4] + x[0], a1 = x[5] + x[1], a2 = x[6] + x[2], a3 = x[7] + x[3];
+  float b0 = a0 + a2, b1 = a1 + a3;
+  return b0 + b1;
+}
+float hsum4(const float *x) {
+  float b0 = x[0] + x[2], b1 = x[1] + x[3];
+  return b0 + b1;
+}
+float dot_x86_order(const float *a, const float *b, size_t n) {
+  if (n >= 32) {
+    size_t m = n - n % 32;
+    float acc[32] = {0};
+    for (size_t i = 0; i < m; i += 32)
+      for (int j = 0; j < 32; j++) acc[j] = fmaf(a[i + j], b[i + j], acc[j]);
+    float r = hsum8(acc) + hsum8(acc + 8) + hsum8(acc + 16) + hsum8(acc + 24);
+    for (size_t i = m; i < n; i++) {
+      float p = a[i] * b[i];
+      r += p;
+    }
+    return r;
+  }
+  if (n >= 16) {
+    size_t m = n - n % 16;
+    float acc[16] = {0};
+    for (size_t i = 0; i < m; i += 16)
+      for (int j = 0; j < 16; j++) {
+        float p = a[i + j] * b[i + j];
+        acc[j] = p + acc[j];
+      }
+    float r = hsum4(acc) + hsum4(acc + 4) + hsum4(acc + 8) + hsum4(acc + 12);
+    for (size_t i = m; i < n; i++) {
+      float p = a[i] * b[i];
+      r += p;
+    }
+    return r;
+  }
+  float s = 0.f;
+  for (size_t i = 0; i < n; i++) {
+    float p = a[i] * b[i];
+    s = s + p;
+  }
+  return s;
+}
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (!count) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct hny_builder {
+  hny_build_opts o{};
+  uint32_t n = 0;
+  std::vector<uint32_t> ids;
+  std::vector<uint8_t> level;
+  std::vector<uint32_t> order;        // insertion order (slots), level desc, id asc inside a level
+  std::vector<uint32_t> entry_points; // slots ascending
+  std::vector<int32_t> upper_idx;
+  uint32_t max_level = 0, n_upper = 0;
+  LaunchShape shape{64, 1};
+  double frac = 0.0;
+  uint32_t bmax = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // schedule state
+  size_t pos = 0;
+  uint64_t n_done = 0, n_batches = 0;
+  hny_batch cur{};
+  bool in_batch = false, finalized = false;
+  // device memory
+  GraphDev g{};
+  DevBuf<unsigned char> d_rows, d_level;
+  DevBuf<float> d_norms, d_l0_dist, d_up_dist;
+  DevBuf<int> d_upper_idx;
+  DevBuf<u32> d_l0_ids, d_l0_cnt, d_up_ids, d_up_cnt, d_order, d_eps, d_bits, d_vlog, d_cand_n,
+      d_seg_start, d_nseg;
+  DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
+  DevBuf<unsigned char> d_sort_tmp;
+  size_t sort_tmp_bytes = 0;
+  uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
+  size_t max_ops = 0, sel_words = 0;
+  double t_upload = 0, t_build0 = 0, t_build = 0;
+};
+
+namespace {
+
+int pick_shape(int metric, uint32_t dim, LaunchShape &s, uint32_t &n16) {
+  n16 = is_binary(metric) ? (uint32_t)((vec_bytes(metric, dim) + 15) / 16) : (dim + 3) / 4;
+  uint32_t l = pow2ceil(n16);
+  if (l < 8) l = 8;
+  if (l > 64) l = 64;
+  uint32_t c = (n16 + l - 1) / l;
+  static const uint32_t set[] = {1, 2, 3, 4, 6, 8};
+  for (uint32_t v : set)
+    if (c <= v) {
+      s.lpr = (int)l;
+      s.nch = (int)v;
+      return HNY_OK;
+    }
+  return fail(HNY_ERR_UNSUPPORTED, "dim %u needs more than 8 chunks per lane (max f32 dim 2048)", dim);
+}
+
+int mclass_of(int metric) {
+  switch (metric) {
+    case HNY_COSINE: return MC_DOT;
+    case HNY_EUCLIDEAN: return MC_L2;
+    case HNY_MANHATTAN: return MC_L1;
+    default: return MC_BIN;
+  }
+}
+
+uint32_t cap_of(const hny_builder *b, uint32_t layer_or_level) {
+  return layer_or_level == 0 ? b->o.M0 : b->o.M; // hnsw.rs:540, 572
+}
+
+int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// codec bytes -> zero padded device rows (UnalignedVector is byte-packed and unaligned inside
+// LMDB pages, f32.rs:9-55; the device wants 16-byte aligned rows)
+int upload_rows(const void *vectors, size_t stride, size_t vbytes, uint64_t n, uint32_t row_stride,
+                unsigned char *dst, hipStream_t st) {
+  if (stride == row_stride && vbytes == row_stride) {
+    HIP_TRY(hipMemcpyAsync(dst, vectors, (size_t)n * row_stride, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HNY_OK;
+  }
+  const size_t chunk_rows = std::max<size_t>(1, (64u << 20) / row_stride);
+  std::vector<unsigned char> stage(chunk_rows * row_stride);
+  for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+    size_t cnt = (size_t)std::min<uint64_t>(chunk_rows, n - r0);
+    std::fill(stage.begin(), stage.begin() + cnt * row_stride, 0);
+    for (size_t r = 0; r < cnt; r++)
+      memcpy(&stage[r * row_stride], (const unsigned char *)vectors + (r0 + r) * stride, vbytes);
+    HIP_TRY(hipMemcpyAsync(dst + r0 * row_stride, stage.data(), cnt * row_stride,
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return HNY_OK;
+}
+
+int reset_graph(hny_builder *b) {
+  hipStream_t st = b->stream;
+  HIP_TRY(hnyk_fill_u32(b->d_l0_ids.p, HNY_SENT, b->d_l0_ids.n, st));
+  HIP_TRY(hipMemsetAsync(b->d_l0_cnt.p, 0, b->d_l0_cnt.n * 4, st));
+  HIP_TRY(hipMemsetAsync(b->d_l0_dist.p, 0, b->d_l0_dist.n * 4, st));
+  if (b->d_up_ids.n) {
+    HIP_TRY(hnyk_fill_u32(b->d_up_ids.p, HNY_SENT, b->d_up_ids.n, st));
+    HIP_TRY(hipMemsetAsync(b->d_up_cnt.p, 0, b->d_up_cnt.n * 4, st));
+    HIP_TRY(hipMemsetAsync(b->d_up_dist.p, 0, b->d_up_dist.n * 4, st));
+  }
+  HIP_TRY(hipMemsetAsync(b->d_stats.p, 0, ST_COUNT * 8, st));
+  HIP_TRY(hipMemsetAsync(b->d_bits.p, 0, b->d_bits.n * 4, st));
+  b->pos = 0;
+  b->n_done = 0;
+  b->n_batches = 0;
+  b->in_batch = false;
+  b->finalized = false;
+  b->t_build0 = now_s();
+  return HNY_OK;
+}
+
+size_t group_end(const hny_builder *b, size_t pos) {
+  size_t e = pos;
+  while (e < b->n && b->level[b->order[e]] == b->level[b->order[pos]]) e++;
+  return e;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *hny_last_error(void) { return g_err.c_str(); }
+const char *hny_version(void) { return "hannoy_amd 0.1.0 (gfx950)"; }
+
+size_t hny_vector_bytes(int32_t metric, uint32_t dim) { return vec_bytes(metric, dim); }
+size_t hny_header_bytes(int32_t metric) { return hdr_bytes(metric); }
+
+uint32_t hny_batch_size(double frac, uint32_t bmax, uint64_t n_done) {
+  if (bmax == 0) return 1;
+  double v = std::floor(frac * (double)n_done);
+  if (v < 1.0) v = 1.0;
+  if (v > (double)bmax) v = (double)bmax;
+  return (uint32_t)v;
+}
+
+// UnalignedVectorCodec::from_slice + Distance::new_header (host; ingest is not on the timed path)
+int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *vectors, void *out_codes,
+                       void *out_headers) {
+  if (!vectors || !out_codes || !out_headers || metric < 0 || metric > HNY_BQ_MANHATTAN || dim == 0)
+    return fail(HNY_ERR_INVALID_ARG, "hny_encode_vectors: bad argument");
+  const size_t vb = vec_bytes(metric, dim), hb = hdr_bytes(metric);
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 4096) nt = 1;
+  auto work = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      const float *v = vectors + i * dim;
+      unsigned char *code = (unsigned char *)out_codes + i * vb;
+      unsigned char *hdr = (unsigned char *)out_headers + i * hb;
+      if (!is_binary(metric)) {
+        memcpy(code, v, vb); // f32.rs:9-55 raw native-endian bytes
+        float h = 0.0f;      // bias = 0.0 (euclidean.rs:38-40, manhattan.rs:37-39)
+        if (metric == HNY_COSINE) h = sqrtf(dot_x86_order(v, v, dim)); // cosine.rs:36-38,58-60
+        memcpy(hdr, &h, 4);
+        continue;
+      }
+      uint32_t ones = 0;
+      for (uint32_t base = 0; base < dim; base += 64) {
+        uint64_t word = 0;
+        uint32_t cnt = std::min<uint32_t>(64, dim - base);
+        for (uint32_t k = 0; k < cnt; k++) {
+          uint32_t bits;
+          memcpy(&bits, &v[base + k], 4);
+          // binary.rs:87-89: 0 < bits < 0x8000_0000 ; binary_quantized.rs:86: is_sign_positive
+          bool one = metric == HNY_HAMMING ? (bits < 0x80000000u && bits > 0u) : (bits >> 31) == 0;
+          if (one) word |= 1ull << k; // dim i -> bit (i mod 64), LSB first
+        }
+        memcpy(code + (base / 64) * 8, &word, 8);
+        ones += (uint32_t)__builtin_popcountll(word);
+      }
+      if (metric == HNY_HAMMING) {
+        uint64_t z = 0; // hamming.rs:40-42 idx = 0usize
+        memcpy(hdr, &z, 8);
+      } else {
+        float h = 0.0f;
+        // binary_quantized_cosine.rs:40-42,61-63: sqrt(dot_bq(v,v)) = sqrt(padded dims)
+        if (metric == HNY_BQ_COSINE) h = sqrtf((float)(int32_t)(vb * 8));
+        memcpy(hdr, &h, 4);
+      }
+      (void)ones;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+  for (auto &t : th) t.join();
+  return HNY_OK;
+}
+
+void hny_builder_destroy(hny_builder *b) {
+  if (!b) return;
+  if (b->stream) {
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    (void)hipStreamDestroy(b->stream);
+  }
+  delete b;
+}
+
+int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out) {
+  if (!opts || !items || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  const hny_build_opts &o = *opts;
+  if (o.metric < 0 || o.metric > HNY_BQ_MANHATTAN) return fail(HNY_ERR_INVALID_ARG, "bad metric");
+  if (o.dim == 0) return fail(HNY_ERR_INVALID_DIM, "dim must be > 0");
+  if (o.M == 0 || o.M0 < o.M) return fail(HNY_ERR_INVALID_ARG, "need 1 <= M <= M0");
+  if (o.M0 > HNY_MAX_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_MAX_CAP);
+  if (o.ef_construction == 0 || o.ef_construction > HNY_MAX_EF)
+    return fail(HNY_ERR_UNSUPPORTED, "ef_construction %u outside [1, %d]", o.ef_construction,
+                HNY_MAX_EF);
+  if (items->n >= (1ull << 31)) return fail(HNY_ERR_UNSUPPORTED, "n >= 2^31");
+  const size_t vb = vec_bytes(o.metric, o.dim), hb = hdr_bytes(o.metric);
+  if (items->n && (!items->ids || !items->vectors || !items->headers))
+    return fail(HNY_ERR_INVALID_ARG, "null item arrays");
+  if (items->n && items->stride < vb)
+    return fail(HNY_ERR_INVALID_DIM, "stride %zu < %zu codec bytes for dim %u", items->stride, vb,
+                o.dim); // Error::InvalidVecDimension
+  if (items->n && items->header_size != hb)
+    return fail(HNY_ERR_INVALID_ARG, "header_size %zu, expected %zu", items->header_size, hb);
+  for (uint64_t i = 1; i < items->n; i++)
+    if (items->ids[i] <= items->ids[i - 1]) return fail(HNY_ERR_INVALID_ARG, "ids not ascending");
+
+  auto b = std::unique_ptr<hny_builder, void (*)(hny_builder *)>(new hny_builder(), hny_builder_destroy);
+  b->o = o;
+  b->n = (uint32_t)items->n;
+  const uint32_t n = b->n;
+  b->frac = o.batch_frac > 0.0 ? o.batch_frac : 0.02;
+  b->bmax = o.batch_max ? o.batch_max : 16384u;
+  uint32_t n16;
+  int rc = pick_shape(o.metric, o.dim, b->shape, n16);
+  if (rc) return rc;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(HNY_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+  if (o.device >= 0) {
+    b->device = o.device;
+    HIP_TRY(hipSetDevice(b->device));
+  } else {
+    HIP_TRY(hipGetDevice(&b->device));
+  }
+  HIP_TRY(hipStreamCreate(&b->stream));
+  hipStream_t st = b->stream;
+  double t0 = now_s();
+
+  // ---- levels (hnsw.rs:141-149) ----
+  b->ids.assign(items->ids, items->ids + n);
+  b->level.resize(n);
+  if (items->levels) {
+    memcpy(b->level.data(), items->levels, n);
+  } else {
+    std::vector<float> p = level_probas(o.M);
+    std::vector<double> cum(p.size());
+    double tot = 0;
+    for (size_t i = 0; i < p.size(); i++) cum[i] = (tot += p[i]);
+    SplitMix64 rng{o.seed};
+    for (uint32_t s = 0; s < n; s++) { // one draw per item in ascending id order
+      double u = (double)(rng.next() >> 11) * (1.0 / 9007199254740992.0) * tot;
+      size_t l = std::upper_bound(cum.begin(), cum.end(), u) - cum.begin();
+      b->level[s] = (uint8_t)std::min(l, p.size() - 1);
+    }
+  }
+  // ---- prepare_levels_and_entry_points, fresh DB (hnsw.rs:222-289) ----
+  b->order.resize(n);
+  for (uint32_t s = 0; s < n; s++) b->order[s] = s;
+  std::stable_sort(b->order.begin(), b->order.end(),
+                   [&](uint32_t x, uint32_t y) { return b->level[x] > b->level[y]; });
+  b->max_level = n ? b->level[b->order[0]] : 0;
+  if (b->max_level > 7) return fail(HNY_ERR_INVALID_ARG, "level > 7");
+  b->upper_idx.assign(n, -1);
+  for (uint32_t s = 0; s < n; s++) {
+    if (b->level[s] == b->max_level) b->entry_points.push_back(s);
+    if (b->level[s] >= 1) b->upper_idx[s] = (int32_t)b->n_upper++;
+  }
+  if (b->entry_points.size() > HNY_MAX_EPS)
+    return fail(HNY_ERR_UNSUPPORTED, "%zu entry points > %d", b->entry_points.size(), HNY_MAX_EPS);
+
+  // ---- sizes ----
+  b->rcap = 64;
+  while (b->rcap < std::max<uint32_t>(o.ef_construction, (uint32_t)b->entry_points.size()) + 1) b->rcap *= 2;
+  b->max_batch = 1;
+  b->max_ops = 2;
+  b->sel_words = 2;
+  for (size_t pos = 0; pos < n;) {
+    size_t e = group_end(b.get(), pos);
+    uint32_t L = b->level[b->order[pos]];
+    uint64_t bs = std::min<uint64_t>(b->bmax, e - pos);
+    uint64_t cs = cap_of(b.get(), L);
+    b->max_batch = std::max<uint32_t>(b->max_batch, (uint32_t)bs);
+    b->max_ops = std::max<size_t>(b->max_ops, (size_t)(bs * (L + 1) * cs * 2));
+    b->sel_words = std::max<size_t>(b->sel_words, (size_t)(bs * (L + 1) * (cs + 1)));
+    pos = e;
+  }
+  if (b->max_ops >= (1ull << 30))
+    return fail(HNY_ERR_UNSUPPORTED, "batch_max too large: %zu link ops per batch >= 2^30", b->max_ops);
+  b->walk_slots = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_WALK_SLOTS", 4096)), 65536);
+  b->bits_words = (n + 31) / 32 + 1;
+  b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
+
+  // ---- device memory ----
+  GraphDev &g = b->g;
+  g.n = n;
+  g.metric = o.metric;
+  g.mclass = mclass_of(o.metric);
+  g.n16 = n16;
+  g.row_stride = n16 * 16;
+  g.bin_bits = (u32)(vb * 8);
+  g.M = o.M;
+  g.M0 = o.M0;
+  g.max_level = b->max_level;
+  g.n_upper = b->n_upper;
+  g.alpha = o.alpha;
+  const size_t nn = std::max<uint32_t>(n, 1);
+  HIP_TRY(b->d_rows.alloc(nn * g.row_stride));
+  HIP_TRY(b->d_level.alloc(nn));
+  HIP_TRY(b->d_upper_idx.alloc(nn));
+  const bool has_norm = o.metric == HNY_COSINE || o.metric == HNY_BQ_COSINE;
+  if (has_norm) HIP_TRY(b->d_norms.alloc(nn));
+  HIP_TRY(b->d_l0_ids.alloc(nn * o.M0));
+  HIP_TRY(b->d_l0_dist.alloc(nn * o.M0));
+  HIP_TRY(b->d_l0_cnt.alloc(nn));
+  const size_t nup = (size_t)b->n_upper * std::max<uint32_t>(b->max_level, 1);
+  HIP_TRY(b->d_up_ids.alloc(nup * o.M));
+  HIP_TRY(b->d_up_dist.alloc(nup * o.M));
+  HIP_TRY(b->d_up_cnt.alloc(nup));
+  HIP_TRY(b->d_order.alloc(nn));
+  HIP_TRY(b->d_eps.alloc(HNY_MAX_EPS));
+  HIP_TRY(b->d_stats.alloc(ST_COUNT));
+  const uint32_t slots = std::min<uint32_t>(b->walk_slots, std::max<uint32_t>(b->max_batch, 256));
+  b->walk_slots = slots;
+  HIP_TRY(b->d_bits.alloc((size_t)slots * b->bits_words));
+  HIP_TRY(b->d_vlog.alloc((size_t)slots * b->log_cap));
+  HIP_TRY(b->d_sel.alloc(b->sel_words));
+  const size_t cand_rows = std::max<uint32_t>(b->max_batch, 256);
+  HIP_TRY(b->d_cand.alloc(cand_rows * b->rcap));
+  HIP_TRY(b->d_cand_n.alloc(cand_rows));
+  HIP_TRY(b->d_keys_a.alloc(b->max_ops));
+  HIP_TRY(b->d_keys_b.alloc(b->max_ops));
+  HIP_TRY(b->d_vals_a.alloc(b->max_ops));
+  HIP_TRY(b->d_vals_b.alloc(b->max_ops));
+  HIP_TRY(b->d_seg_start.alloc(b->max_ops));
+  HIP_TRY(b->d_nseg.alloc(1));
+  HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
+                          b->d_vals_b.p, (u32)b->max_ops, st));
+  HIP_TRY(b->d_sort_tmp.alloc(b->sort_tmp_bytes + 16));
+
+  g.rows = b->d_rows.p;
+  g.norms = has_norm ? b->d_norms.p : nullptr;
+  g.level = b->d_level.p;
+  g.upper_idx = b->d_upper_idx.p;
+  g.l0_ids = b->d_l0_ids.p;
+  g.l0_dist = b->d_l0_dist.p;
+  g.l0_cnt = b->d_l0_cnt.p;
+  g.up_ids = b->d_up_ids.p;
+  g.up_dist = b->d_up_dist.p;
+  g.up_cnt = b->d_up_cnt.p;
+  g.stats = b->d_stats.p;
+
+  // ---- upload (the "export to HBM" that replaces FrozenReader, parallel.rs:11-45) ----
+  if (n) {
+    rc = upload_rows(items->vectors, items->stride, vb, n, g.row_stride, b->d_rows.p, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->d_level.p, b->level.data(), n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_upper_idx.p, b->upper_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_order.p, b->order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_eps.p, b->entry_points.data(), b->entry_points.size() * 4,
+                           hipMemcpyHostToDevice, st));
+    std::vector<float> norms;
+    if (has_norm) {
+      norms.resize(n);
+      for (uint32_t s = 0; s < n; s++) memcpy(&norms[s], (const unsigned char *)items->headers + (size_t)s * hb, 4);
+      HIP_TRY(hipMemcpyAsync(b->d_norms.p, norms.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  rc = reset_graph(b.get());
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  b->t_upload = now_s() - t0;
+  b->t_build0 = now_s();
+  *out = b.release();
+  return HNY_OK;
+}
+
+int hny_builder_reset(hny_builder *b) {
+  if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
+  HIP_TRY(hipSetDevice(b->device));
+  return reset_graph(b);
+}
+
+int hny_builder_next_batch(hny_builder *b, hny_batch *out) {
+  if (!b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  if (b->in_batch) return fail(HNY_ERR_INVALID_ARG, "previous batch not applied");
+  memset(out, 0, sizeof *out);
+  if (b->pos >= b->n) return HNY_OK;
+  size_t gend = group_end(b, b->pos);
+  uint32_t L = b->level[b->order[b->pos]];
+  uint64_t bs = hny_batch_size(b->frac, b->bmax, b->n_done);
+  bs = std::min<uint64_t>(bs, gend - b->pos);
+  out->first = b->pos;
+  out->count = (uint32_t)bs;
+  out->level = L;
+  out->n_layers = L + 1;
+  out->sel_stride_u64 = (L + 1) * (cap_of(b, L) + 1);
+  b->cur = *out;
+  b->in_batch = true;
+  return HNY_OK;
+}
+
+int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) {
+  if (!b || !b->in_batch) return fail(HNY_ERR_INVALID_ARG, "no current batch");
+  if (lo > hi || hi > b->cur.count) return fail(HNY_ERR_INVALID_ARG, "bad member range");
+  if (lo == hi) return HNY_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  const uint32_t L = b->cur.level, cs = cap_of(b, L);
+  u64 *sel = sel_dev ? (u64 *)sel_dev : b->d_sel.p;
+  const int grid = (int)std::min<uint32_t>(hi - lo, b->walk_slots);
+  for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
+    WalkArgs w{};
+    w.q_slots = b->d_order.p + b->cur.first;
+    w.lo = lo;
+    w.hi = hi;
+    w.layer = (u32)l;
+    w.ef = b->o.ef_construction;
+    w.first = (l == (int32_t)L);
+    w.reader_mode = 0;
+    w.entry_points = b->d_eps.p;
+    w.n_entry_points = (u32)b->entry_points.size();
+    w.sel = sel;
+    w.sel_stride = b->cur.sel_stride_u64;
+    w.cap_sel = cs;
+    w.batch_level = L;
+    w.cand = b->d_cand.p;
+    w.cand_n = b->d_cand_n.p;
+    w.rcap = b->rcap;
+    w.bits = b->d_bits.p;
+    w.bits_words = b->bits_words;
+    w.vlog = b->d_vlog.p;
+    w.log_cap = b->log_cap;
+    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+    PruneArgs p{};
+    p.q_slots = w.q_slots;
+    p.lo = lo;
+    p.hi = hi;
+    p.layer = (u32)l;
+    p.cap = cs; // NB: from the item's top level, hnsw.rs:317
+    p.cand = b->d_cand.p;
+    p.cand_n = b->d_cand_n.p;
+    p.rcap = b->rcap;
+    p.sel = sel;
+    p.sel_stride = b->cur.sel_stride_u64;
+    p.cap_sel = cs;
+    p.batch_level = L;
+    HIP_TRY(hnyk_prune(b->g, p, b->shape, grid, b->stream));
+  }
+  return HNY_OK;
+}
+
+int hny_builder_apply(hny_builder *b, const void *sel_dev) {
+  if (!b || !b->in_batch) return fail(HNY_ERR_INVALID_ARG, "no current batch");
+  HIP_TRY(hipSetDevice(b->device));
+  const uint32_t L = b->cur.level, cs = cap_of(b, L);
+  const u64 *sel = sel_dev ? (const u64 *)sel_dev : b->d_sel.p;
+  const u32 n_ops = b->cur.count * (L + 1) * cs * 2;
+  EmitArgs e{};
+  e.q_slots = b->d_order.p + b->cur.first;
+  e.count = b->cur.count;
+  e.sel = sel;
+  e.sel_stride = b->cur.sel_stride_u64;
+  e.cap_sel = cs;
+  e.batch_level = L;
+  e.keys = b->d_keys_a.p;
+  e.vals = b->d_vals_a.p;
+  HIP_TRY(hnyk_emit(b->g, e, b->stream));
+  size_t tmp = b->sort_tmp_bytes;
+  HIP_TRY(hnyk_sort_pairs(b->d_sort_tmp.p, tmp, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
+                          b->d_vals_b.p, n_ops, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_nseg.p, 0, 4, b->stream));
+  HIP_TRY(hnyk_segments(b->d_keys_b.p, n_ops, b->d_seg_start.p, b->d_nseg.p, b->stream));
+  ApplyArgs a{};
+  a.keys = b->d_keys_b.p;
+  a.vals = b->d_vals_b.p;
+  a.n_ops = n_ops;
+  a.seg_start = b->d_seg_start.p;
+  a.n_seg = b->d_nseg.p;
+  const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
+  HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream));
+  b->pos += b->cur.count;
+  b->n_done += b->cur.count;
+  b->n_batches++;
+  b->in_batch = false;
+  return HNY_OK;
+}
+
+int hny_builder_sync(hny_builder *b) {
+  if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return HNY_OK;
+}
+
+void hny_graph_free(hny_graph *g) {
+  if (!g) return;
+  free((void *)g->rec_item);
+  free((void *)g->rec_layer);
+  free((void *)g->rec_offset);
+  free((void *)g->neighbours);
+  free((void *)g->entry_points);
+  free(g);
+}
+
+// the write loop's input (hnsw.rs:191-213): one record per (item, layer), ids deduplicated
+int hny_builder_finish(hny_builder *b, hny_graph **out) {
+  if (!b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (b->pos < b->n || b->in_batch) return fail(HNY_ERR_INVALID_ARG, "build not finished");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->t_build = now_s() - b->t_build0;
+  double t0 = now_s();
+  const uint32_t n = b->n, M = b->o.M, M0 = b->o.M0, ml = b->max_level;
+  u64 stats[ST_COUNT] = {0};
+  HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
+    return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
+                stats[ST_ERR_ITER]);
+  std::vector<u32> l0((size_t)n * M0), up((size_t)b->n_upper * std::max(ml, 1u) * M);
+  if (n) HIP_TRY(hipMemcpy(l0.data(), b->d_l0_ids.p, l0.size() * 4, hipMemcpyDeviceToHost));
+  if (!up.empty()) HIP_TRY(hipMemcpy(up.data(), b->d_up_ids.p, up.size() * 4, hipMemcpyDeviceToHost));
+
+  // every inserted item owns a (possibly empty) record on layers 0..=level (add_in_layers_below,
+  // hnsw.rs:419-424)
+  std::vector<uint64_t> rec_first(n + 1, 0);
+  for (uint32_t s = 0; s < n; s++) rec_first[s + 1] = rec_first[s] + b->level[s] + 1;
+  const uint64_t nrec = rec_first[n];
+  hny_graph *g = (hny_graph *)calloc(1, sizeof(hny_graph));
+  uint32_t *rec_item = (uint32_t *)malloc(std::max<uint64_t>(nrec, 1) * 4);
+  uint8_t *rec_layer = (uint8_t *)malloc(std::max<uint64_t>(nrec, 1));
+  uint64_t *rec_off = (uint64_t *)malloc((nrec + 1) * 8);
+  std::vector<uint32_t> cnt(nrec, 0);
+  std::vector<uint32_t> tmp((size_t)nrec * std::max(M0, M));
+  const size_t tw = std::max(M0, M);
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 10000) nt = 1;
+  auto work = [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t s = lo; s < hi; s++)
+      for (uint32_t l = 0; l <= b->level[s]; l++) {
+        uint64_t r = rec_first[s] + l;
+        rec_item[r] = b->ids[s];
+        rec_layer[r] = (uint8_t)l;
+        const u32 *src = l == 0 ? &l0[(size_t)s * M0]
+                                : &up[((size_t)b->upper_idx[s] * ml + (l - 1)) * M];
+        uint32_t cap = l == 0 ? M0 : M, c = 0;
+        uint32_t *dst = &tmp[r * tw];
+        for (uint32_t k = 0; k < cap && src[k] != HNY_SENT; k++) dst[c++] = b->ids[src[k]];
+        std::sort(dst, dst + c);
+        cnt[r] = (uint32_t)(std::unique(dst, dst + c) - dst); // RoaringBitmap::from_iter
+      }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+      th.emplace_back(work, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt));
+    for (auto &t : th) t.join();
+  }
+  rec_off[0] = 0;
+  for (uint64_t r = 0; r < nrec; r++) rec_off[r + 1] = rec_off[r] + cnt[r];
+  uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
+  for (uint64_t r = 0; r < nrec; r++) memcpy(nbrs + rec_off[r], &tmp[r * tw], (size_t)cnt[r] * 4);
+  uint32_t *eps = (uint32_t *)malloc(std::max<size_t>(b->entry_points.size(), 1) * 4);
+  for (size_t i = 0; i < b->entry_points.size(); i++) eps[i] = b->ids[b->entry_points[i]];
+  g->n_records = nrec;
+  g->rec_item = rec_item;
+  g->rec_layer = rec_layer;
+  g->rec_offset = rec_off;
+  g->neighbours = nbrs;
+  g->entry_points = eps;
+  g->n_entry_points = (uint32_t)b->entry_points.size();
+  g->max_level = ml;
+  g->n_links_added = stats[ST_LINKS];
+  g->n_evals_walk = stats[ST_EVALS_WALK];
+  g->n_evals_prune = stats[ST_EVALS_PRUNE];
+  g->n_evals_apply = stats[ST_EVALS_APPLY];
+  g->n_distance_evals = stats[ST_EVALS_WALK] + stats[ST_EVALS_PRUNE] + stats[ST_EVALS_APPLY];
+  g->n_batches = b->n_batches;
+  g->n_tie_pool_overflow = stats[ST_POOL_OVERFLOW];
+  g->t_upload_s = b->t_upload;
+  g->t_build_s = b->t_build;
+  g->t_export_s = now_s() - t0;
+  *out = g;
+  return HNY_OK;
+}
+
+int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **out) {
+  if (!out) return fail(HNY_ERR_INVALID_ARG, "null out");
+  *out = nullptr;
+  hny_builder *b = nullptr;
+  int rc = hny_builder_create(opts, items, &b);
+  if (rc) return rc;
+  uint64_t since_probe = 0;
+  for (;;) {
+    // cancel: probed between batches, i.e. at least every CANCELLATION_PROBING items as long as
+    // batch_max <= 10 000 ... 16 384 (lib.rs:140, hnsw.rs:174-177)
+    if (opts->cancel && (since_probe == 0 || since_probe >= 10000)) {
+      since_probe = 0;
+      if (opts->cancel(opts->cancel_ctx)) {
+        hny_builder_destroy(b);
+        return fail(HNY_ERR_CANCELLED, "build cancelled");
+      }
+    }
+    hny_batch bt;
+    rc = hny_builder_next_batch(b, &bt);
+    if (rc || bt.count == 0) break;
+    rc = hny_builder_search(b, 0, bt.count, nullptr);
+    if (rc) break;
+    rc = hny_builder_apply(b, nullptr);
+    if (rc) break;
+    since_probe += bt.count;
+    if (opts->progress) opts->progress(opts->progress_ctx, b->n_done, b->n);
+  }
+  if (!rc) rc = hny_builder_finish(b, out);
+  hny_builder_destroy(b);
+  return rc;
+}
+
+int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot_a,
+                          const uint32_t *slot_b, float *out) {
+  if (!b || !slot_a || !slot_b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  if (!n_pairs) return HNY_OK;
+  for (uint64_t i = 0; i < n_pairs; i++)
+    if (slot_a[i] >= b->n || slot_b[i] >= b->n) return fail(HNY_ERR_MISSING_KEY, "slot out of range");
+  HIP_TRY(hipSetDevice(b->device));
+  DevBuf<u32> da, db;
+  DevBuf<float> dout;
+  HIP_TRY(da.alloc(n_pairs));
+  HIP_TRY(db.alloc(n_pairs));
+  HIP_TRY(dout.alloc(n_pairs));
+  HIP_TRY(hipMemcpyAsync(da.p, slot_a, n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(db.p, slot_b, n_pairs * 4, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hnyk_pair_distances(b->g, da.p, db.p, (u32)n_pairs, dout.p, b->shape, b->stream));
+  HIP_TRY(hipMemcpyAsync(out, dout.p, n_pairs * 4, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return HNY_OK;
+}
+
+int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, size_t qstride,
+                           const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
+                           float *out_dists, uint32_t *out_counts) {
+  if (!b || !qvectors || !qheaders || !out_ids || !out_dists || !out_counts || k == 0)
+    return fail(HNY_ERR_INVALID_ARG, "bad argument");
+  if (b->pos < b->n) return fail(HNY_ERR_INVALID_ARG, "build not finished");
+  const uint32_t ef = std::max(ef_search, k); // reader.rs:746
+  if (ef + 1 > b->rcap && ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->n == 0) {
+    for (uint64_t i = 0; i < nq; i++) out_counts[i] = 0; // reader.rs:652-654
+    return HNY_OK;
+  }
+  uint32_t rcap = 64;
+  while (rcap < std::max<uint32_t>(ef, (uint32_t)b->entry_points.size()) + 1) rcap *= 2;
+  const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
+  if (qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
+  const uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
+  DevBuf<unsigned char> dq;
+  DevBuf<float> dqn;
+  DevBuf<u64> dcand;
+  DevBuf<u32> dcn;
+  HIP_TRY(dq.alloc((size_t)chunk * b->g.row_stride));
+  HIP_TRY(dqn.alloc(chunk));
+  HIP_TRY(dcand.alloc((size_t)chunk * rcap));
+  HIP_TRY(dcn.alloc(chunk));
+  const bool has_norm = b->g.norms != nullptr;
+  std::vector<float> qn(chunk);
+  std::vector<u64> hc((size_t)chunk * rcap);
+  std::vector<u32> hn(chunk);
+  for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
+    uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+    int rc = upload_rows((const unsigned char *)qvectors + q0 * qstride, qstride, vb, cnt,
+                         b->g.row_stride, dq.p, b->stream);
+    if (rc) return rc;
+    if (has_norm) {
+      for (uint32_t i = 0; i < cnt; i++) memcpy(&qn[i], (const unsigned char *)qheaders + (q0 + i) * hb, 4);
+      HIP_TRY(hipMemcpyAsync(dqn.p, qn.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, b->stream));
+    }
+    WalkArgs w{};
+    w.q_rows = dq.p;
+    w.q_norms = has_norm ? dqn.p : nullptr;
+    w.q_stride = b->g.row_stride;
+    w.lo = 0;
+    w.hi = cnt;
+    w.layer = 0;
+    w.ef = ef;
+    w.first = 1;
+    w.reader_mode = 1;
+    w.entry_points = b->d_eps.p;
+    w.n_entry_points = (u32)b->entry_points.size();
+    w.cand = dcand.p;
+    w.cand_n = dcn.p;
+    w.rcap = rcap;
+    w.bits = b->d_bits.p;
+    w.bits_words = b->bits_words;
+    w.vlog = b->d_vlog.p;
+    w.log_cap = b->log_cap;
+    HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(cnt, b->walk_slots), b->stream));
+    HIP_TRY(hipMemcpyAsync(hc.data(), dcand.p, (size_t)cnt * rcap * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (uint32_t i = 0; i < cnt; i++) { // drain_asc().take(k), reader.rs:797-798
+      uint32_t c = std::min<uint32_t>(k, hn[i]);
+      for (uint32_t j = 0; j < c; j++) {
+        u64 e = hc[(size_t)i * rcap + j];
+        out_ids[(q0 + i) * k + j] = b->ids[(uint32_t)(e & 0xFFFFFFFFull)];
+        uint32_t db = (uint32_t)(e >> 32);
+        memcpy(&out_dists[(q0 + i) * k + j], &db, 4);
+      }
+      out_counts[q0 + i] = c;
+    }
+  }
+  return HNY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// on-disk records
+// ---------------------------------------------------------------------------------------------
+static void put_key(uint16_t index, uint8_t mode, uint32_t item, uint8_t layer, uint8_t k[8]) {
+  // key.rs:57-66: index u16 BE | mode u8 | item u32 BE | layer u8
+  k[0] = (uint8_t)(index >> 8);
+  k[1] = (uint8_t)index;
+  k[2] = mode;
+  k[3] = (uint8_t)(item >> 24);
+  k[4] = (uint8_t)(item >> 16);
+  k[5] = (uint8_t)(item >> 8);
+  k[6] = (uint8_t)item;
+  k[7] = layer;
+}
+// [3P] roaring 0.10.9 RoaringBitmap::serialize_into: portable format, cookie 12346 (no run
+// containers), u16 key + u16 (card-1) per container, u32 offsets, array (<= 4096) or 8 KiB bitmap
+static void roaring_append(std::vector<uint8_t> &out, const uint32_t *ids, uint64_t n) {
+  struct Ct {
+    uint16_t key;
+    uint64_t b, e;
+  };
+  std::vector<Ct> cs;
+  for (uint64_t i = 0; i < n;) {
+    uint64_t j = i;
+    while (j < n && (ids[j] >> 16) == (ids[i] >> 16)) j++;
+    cs.push_back({(uint16_t)(ids[i] >> 16), i, j});
+    i = j;
+  }
+  auto w16 = [&](uint32_t v) {
+    out.push_back((uint8_t)v);
+    out.push_back((uint8_t)(v >> 8));
+  };
+  auto w32 = [&](uint32_t v) {
+    for (int k = 0; k < 4; k++) out.push_back((uint8_t)(v >> (8 * k)));
+  };
+  w32(12346u);
+  w32((uint32_t)cs.size());
+  for (auto &c : cs) {
+    w16(c.key);
+    w16((uint32_t)(c.e - c.b - 1));
+  }
+  uint32_t off = (uint32_t)(8 + 8 * cs.size());
+  for (auto &c : cs) {
+    w32(off);
+    off += (c.e - c.b) <= 4096 ? (uint32_t)(2 * (c.e - c.b)) : 8192u;
+  }
+  for (auto &c : cs) {
+    if (c.e - c.b <= 4096) {
+      for (uint64_t i = c.b; i < c.e; i++) w16(ids[i] & 0xFFFFu);
+    } else {
+      size_t at = out.size();
+      out.resize(at + 8192, 0);
+      for (uint64_t i = c.b; i < c.e; i++) {
+        uint32_t lo = ids[i] & 0xFFFFu;
+        out[at + (lo >> 3)] |= (uint8_t)(1u << (lo & 7));
+      }
+    }
+  }
+}
+static const char *metric_name(int m) {
+  static const char *names[] = {"cosine", "euclidean", "manhattan", "hamming",
+                                "binary quantized cosine", "binary quantized euclidean",
+                                "binary quantized manhattan"}; // cosine.rs:32-34 ...
+  return names[m];
+}
+
+int hny_encode_kv(const hny_graph *g, const hny_build_opts *opts, const hny_items *items,
+                  uint16_t index, int with_items, hny_kv_sink sink, void *ctx) {
+  if (!g || !opts || !items || !sink) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  uint8_t key[8];
+  std::vector<uint8_t> val;
+  auto emit = [&]() { return sink(ctx, key, 8, val.data(), val.size()); };
+  // Metadata (metadata.rs:28-48)
+  const char *nm = metric_name(opts->metric);
+  val.assign(nm, nm + strlen(nm));
+  val.push_back(0);
+  for (int k = 3; k >= 0; k--) val.push_back((uint8_t)(opts->dim >> (8 * k)));
+  std::vector<uint8_t> rb;
+  roaring_append(rb, items->ids, items->n);
+  for (int k = 3; k >= 0; k--) val.push_back((uint8_t)((uint32_t)rb.size() >> (8 * k)));
+  val.insert(val.end(), rb.begin(), rb.end());
+  for (uint32_t i = 0; i < g->n_entry_points; i++) { // ItemIds::raw_bytes: native-endian u32
+    uint8_t e[4];
+    memcpy(e, &g->entry_points[i], 4);
+    val.insert(val.end(), e, e + 4);
+  }
+  val.push_back((uint8_t)g->max_level);
+  put_key(index, 0, 0, 0, key);
+  if (int rc = emit()) return rc;
+  // Version (version.rs:36-48): crate version 0.1.3
+  val.clear();
+  for (uint32_t x : {0u, 1u, 3u})
+    for (int k = 3; k >= 0; k--) val.push_back((uint8_t)(x >> (8 * k)));
+  put_key(index, 0, 1, 0, key);
+  if (int rc = emit()) return rc;
+  // Links (node.rs:141-144)
+  for (uint64_t r = 0; r < g->n_records; r++) {
+    val.assign(1, 1);
+    roaring_append(val, g->neighbours + g->rec_offset[r], g->rec_offset[r + 1] - g->rec_offset[r]);
+    put_key(index, 2, g->rec_item[r], g->rec_layer[r], key);
+    if (int rc = emit()) return rc;
+  }
+  // Items (node.rs:136-140)
+  if (with_items) {
+    const size_t vb = vec_bytes(opts->metric, opts->dim), hb = items->header_size;
+    for (uint64_t s = 0; s < items->n; s++) {
+      val.assign(1 + hb + vb, 0);
+      memcpy(val.data() + 1, (const uint8_t *)items->headers + s * hb, hb);
+      memcpy(val.data() + 1 + hb, (const uint8_t *)items->vectors + s * items->stride, vb);
+      put_key(index, 3, items->ids[s], 0, key);
+      if (int rc = emit()) return rc;
+    }
+  }
+  return HNY_OK;
+}
+
+} // extern "C"

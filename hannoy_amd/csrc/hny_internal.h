@@ -1,0 +1,130 @@
+// hny_internal.h — shared between the host driver (hny_host.cpp) and the gfx950 kernels
+// (hny_kernels.hip).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define HNY_SENT 0xFFFFFFFFu      // empty neighbour slot
+#define HNY_MAX_CAP 64            // max(M, M0): one lane per neighbour
+#define HNY_MAX_EPS 64            // max entry points / eps per walk
+#define HNY_POOL_CAP 128          // tie pool (DESIGN.md "candidate heap")
+#define HNY_MAX_EF 512
+#define HNY_OP_INVALID 0xFFFFFFFFFFFFFFFFull
+
+// metric classes of the inner loop
+enum { MC_DOT = 0, MC_L2 = 1, MC_L1 = 2, MC_BIN = 3 };
+
+// device-side error / statistics words
+enum {
+  ST_EVALS_WALK = 0,
+  ST_EVALS_PRUNE = 1,
+  ST_EVALS_APPLY = 2,
+  ST_LINKS = 3,
+  ST_POOL_OVERFLOW = 4,
+  ST_LOG_OVERFLOW = 5,
+  ST_ERR_RES_OVERFLOW = 6,
+  ST_ERR_ITER = 7,
+  ST_COUNT = 16
+};
+
+struct GraphDev {
+  // items (resident in HBM for the whole build)
+  u32 n;
+  int metric;       // hny_metric
+  int mclass;       // MC_*
+  u32 n16;          // 16-byte units per row that carry data
+  u32 row_stride;   // bytes, multiple of 16
+  u32 bin_bits;     // binary codecs: padded dims = vector bytes * 8
+  const unsigned char *rows;
+  const float *norms; // header norm (cosine / bq cosine), else unused
+  const unsigned char *level;
+  const int *upper_idx; // slot -> index among items with level >= 1, or -1
+  // graph
+  u32 M, M0, max_level, n_upper;
+  float alpha;
+  u32 *l0_ids;   // [n][M0], HNY_SENT beyond the count
+  float *l0_dist; // [n][M0]
+  u32 *l0_cnt;   // [n] low 16 bits = count, bit 31 = frozen (full and self-pruned to full)
+  u32 *up_ids;   // [n_upper][max_level][M]
+  float *up_dist;
+  u32 *up_cnt;   // [n_upper][max_level]
+  u64 *stats;    // [ST_COUNT]
+};
+
+struct WalkArgs {
+  // queries: build mode -> stored items q_slots[member]; knn mode -> external rows
+  const u32 *q_slots;
+  const unsigned char *q_rows; // knn mode (else null)
+  const float *q_norms;
+  u32 q_stride;
+  u32 lo, hi;       // member range
+  u32 layer;        // layer of the ef walk
+  u32 ef;
+  int first;        // 1: start from the entry points and descend greedily to `layer`
+  int reader_mode;  // Reader::hnsw_search visited-set semantics (reader.rs:731-743)
+  const u32 *entry_points;
+  u32 n_entry_points;
+  // eps source when !first: selection of layer+1
+  const u64 *sel;
+  u32 sel_stride, cap_sel, batch_level;
+  // output: sorted (dist bits << 32 | slot) lists
+  u64 *cand;
+  u32 *cand_n;
+  u32 rcap;         // capacity of res in LDS and of cand rows
+  // per-block workspace
+  u32 *bits;        // [grid][bits_words]
+  u32 bits_words;
+  u32 *vlog;        // [grid][log_cap]
+  u32 log_cap;
+};
+
+struct PruneArgs {
+  const u32 *q_slots;
+  u32 lo, hi;
+  u32 layer;
+  u32 cap;          // cap chosen from the item's top level (hnsw.rs:317 quirk)
+  const u64 *cand;
+  const u32 *cand_n;
+  u32 rcap;
+  u64 *sel;
+  u32 sel_stride, cap_sel, batch_level;
+};
+
+struct EmitArgs {
+  const u32 *q_slots;
+  u32 count;
+  const u64 *sel;
+  u32 sel_stride, cap_sel, batch_level;
+  u64 *keys;  // [count * n_layers * cap_sel * 2]
+  u64 *vals;
+};
+
+struct ApplyArgs {
+  const u64 *keys; // sorted
+  const u64 *vals;
+  u32 n_ops;
+  const u32 *seg_start;
+  const u32 *n_seg;
+};
+
+struct LaunchShape {
+  int lpr; // lanes per row: 8,16,32,64
+  int nch; // 16-byte chunks per lane: 1,2,3,4,6,8
+};
+
+// kernels' host launchers (hny_kernels.hip)
+hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st);
+hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st);
+hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
+                           u64 *vals_out, u32 n, hipStream_t st);
+hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
+                               LaunchShape s, hipStream_t st);
+hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);
+size_t hnyk_walk_lds_bytes(u32 rcap);

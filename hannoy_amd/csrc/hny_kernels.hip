@@ -1,0 +1,902 @@
+// hny_kernels.hip — gfx950 (CDNA4, wave64) kernels of the HNSW build hot path.
+//
+//   k_walk   : walk_layer          (/root/reference/src/hnsw.rs:460-518) + greedy descent (:303-307)
+//              and Reader visit     (/root/reference/src/reader.rs:301-369, 722-767)
+//   k_prune  : robust_prune        (hnsw.rs:565-597)
+//   k_emit / k_segments / k_apply : add_link, both directions (hnsw.rs:316-324, 523-560)
+//   distances: src/distance/*.rs over src/spaces/simple*.rs (K1..K13 of SURVEY.md §2.1)
+//
+// Execution model: one wave64 == one workgroup == one query / prune job / link target.  All
+// bookkeeping values (lengths, positions, candidate ids) are wave-uniform; candidate rows are
+// streamed from HBM with 16-byte-per-lane coalesced loads, LPR lanes per row, several rows in
+// flight per wave; the beam (res), the tie pool and the neighbour frontier live in LDS; the visited
+// set is a per-wave bitset in HBM updated with atomicOr (replaces the RoaringBitmap, hnsw.rs:471).
+// HBM-bound integer/f32 streaming work: no MFMA (see DESIGN.md for why).
+#include "hny_internal.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+// block == one wave: with __launch_bounds__(64) the barrier is a wave-level fence only
+#define WSYNC() __syncthreads()
+
+namespace {
+
+__device__ __forceinline__ u32 fbits(float f) { return __float_as_uint(f); }
+
+// ---------------------------------------------------------------------------------------------
+// distance inner loops.  Lane t of an LPR-lane group owns 16-byte unit #(c*LPR + t), c < NCH.
+// f32 ("wave order", restated in oracle/hannoy_oracle.cpp wave_reduce): one fma chain per lane
+// over its 4*NCH elements in index order, then an xor butterfly LPR/2 .. 1.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__device__ __forceinline__ void load_row(const unsigned char *p, int t, u32 n16, float4 (&r)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    u32 f = (u32)(c * LPR + t);
+    r[c] = f < n16 ? *reinterpret_cast<const float4 *>(p + (size_t)f * 16)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int NCH>
+__device__ __forceinline__ float partial_f32(int mclass, const float4 (&q)[NCH],
+                                             const float4 (&r)[NCH]) {
+  float acc = 0.f;
+  if (mclass == MC_DOT) { // K1 dot_product (simple_avx.rs:69-110 computes the same sum)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      acc = __builtin_fmaf(q[c].x, r[c].x, acc);
+      acc = __builtin_fmaf(q[c].y, r[c].y, acc);
+      acc = __builtin_fmaf(q[c].z, r[c].z, acc);
+      acc = __builtin_fmaf(q[c].w, r[c].w, acc);
+    }
+  } else if (mclass == MC_L2) { // K2 squared euclidean (simple_avx.rs:17-65)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float d0 = q[c].x - r[c].x, d1 = q[c].y - r[c].y, d2 = q[c].z - r[c].z, d3 = q[c].w - r[c].w;
+      acc = __builtin_fmaf(d0, d0, acc);
+      acc = __builtin_fmaf(d1, d1, acc);
+      acc = __builtin_fmaf(d2, d2, acc);
+      acc = __builtin_fmaf(d3, d3, acc);
+    }
+  } else { // K10 manhattan (manhattan.rs:41-43)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      acc = acc + __builtin_fabsf(q[c].x - r[c].x);
+      acc = acc + __builtin_fabsf(q[c].y - r[c].y);
+      acc = acc + __builtin_fabsf(q[c].z - r[c].z);
+      acc = acc + __builtin_fabsf(q[c].w - r[c].w);
+    }
+  }
+  return acc;
+}
+
+// K11..K13: popcount(u ^ v) (hamming.rs:55-85, simple.rs:119-131, binary_quantized_*.rs)
+template <int NCH>
+__device__ __forceinline__ u32 partial_bin(const float4 (&q)[NCH], const float4 (&r)[NCH]) {
+  u32 pc = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    pc += __popc(__float_as_uint(q[c].x) ^ __float_as_uint(r[c].x));
+    pc += __popc(__float_as_uint(q[c].y) ^ __float_as_uint(r[c].y));
+    pc += __popc(__float_as_uint(q[c].z) ^ __float_as_uint(r[c].z));
+    pc += __popc(__float_as_uint(q[c].w) ^ __float_as_uint(r[c].w));
+  }
+  return pc;
+}
+
+template <int LPR>
+__device__ __forceinline__ float butterfly_f32(float v) {
+#pragma unroll
+  for (int off = LPR / 2; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ u32 butterfly_u32(u32 v) {
+#pragma unroll
+  for (int off = LPR / 2; off >= 1; off >>= 1) v = v + (u32)__shfl_xor((int)v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float finalize_f32(const GraphDev &g, float acc, float qn, float rn) {
+  if (g.metric == 0 /*HNY_COSINE, cosine.rs:40-56*/) {
+    float pnqn = qn * rn;
+    if (pnqn > 1.1920929e-07f) {
+      float c = acc / pnqn;
+      if (c < -1.0f) c = -1.0f;
+      if (c > 1.0f) c = 1.0f;
+      return (1.0f - c) / 2.0f;
+    }
+    return 0.0f;
+  }
+  return acc; // squared L2 (euclidean.rs:42-44) / L1
+}
+
+__device__ __forceinline__ float finalize_bin(const GraphDev &g, u32 pop, float qn, float rn) {
+  switch (g.metric) {
+    case 3: // hamming.rs:44-47: popcount / padded dims
+      return (float)pop / (float)g.bin_bits;
+    case 4: { // binary_quantized_cosine.rs:44-59
+      float pq = (float)((int)g.bin_bits - 2 * (int)pop);
+      float pnqn = qn * rn;
+      if (pnqn != 0.0f) {
+        float c = pq / pnqn;
+        return (1.0f - c) / 2.0f;
+      }
+      return 0.0f;
+    }
+    case 5: // binary_quantized_euclidean.rs:76-83
+      return (float)(pop * 4u);
+    default: // binary_quantized_manhattan.rs:72-79
+      return (float)(pop * 2u);
+  }
+}
+
+template <int NCH>
+struct RowsInFlight {
+  // 16-byte loads in flight per lane ~ 12..16
+  static constexpr int U = NCH >= 6 ? 2 : (NCH >= 3 ? 4 : (NCH == 2 ? 6 : 8));
+};
+
+// distances from the query (registers) to rows ids[0..n) (LDS) -> out[0..n) (LDS).
+// D::distance at hnsw.rs:476,503,584.
+template <int LPR, int NCH>
+__device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[NCH], float qn,
+                                          const u32 *ids, int n, float *out) {
+  constexpr int RPG = 64 / LPR;               // rows per wave-wide load instruction
+  constexpr int U = RowsInFlight<NCH>::U;     // load groups in flight
+  constexpr int RPI = RPG * U;
+  const int ln = threadIdx.x, t = ln % LPR, sub = ln / LPR;
+  for (int k0 = 0; k0 < n; k0 += RPI) {
+    float4 r[U][NCH];
+    float rn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      rn[u] = 0.f;
+      if (k0 + u * RPG < n) { // wave-uniform
+        int ri = k0 + u * RPG + sub;
+        if (ri > n - 1) ri = n - 1;
+        u32 rid = ids[ri];
+        if (LPR == 64) rid = __builtin_amdgcn_readfirstlane(rid);
+        const unsigned char *p = g.rows + (size_t)rid * g.row_stride;
+        load_row<LPR, NCH>(p, t, g.n16, r[u]);
+        if (g.norms) rn[u] = g.norms[rid];
+      } else {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) r[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (k0 + u * RPG < n) {
+        float d;
+        if (g.mclass == MC_BIN) {
+          u32 pc = butterfly_u32<LPR>(partial_bin<NCH>(q, r[u]));
+          d = finalize_bin(g, pc, qn, rn[u]);
+        } else {
+          float pa = butterfly_f32<LPR>(partial_f32<NCH>(g.mclass, q, r[u]));
+          d = finalize_f32(g, pa, qn, rn[u]);
+        }
+        int ri = k0 + u * RPG + sub;
+        if (t == 0 && ri < n) out[ri] = d;
+      }
+    }
+  }
+}
+
+// neighbour list of (layer, node): ids in insertion order, HNY_SENT beyond the count
+// (get_neighbours, hnsw.rs:428-456, fresh DB: in-memory lists only)
+__device__ __forceinline__ const u32 *nbr_ids(const GraphDev &g, u32 layer, u32 node, u32 &cap) {
+  if (layer == 0) {
+    cap = g.M0;
+    return g.l0_ids + (size_t)node * g.M0;
+  }
+  int ui = g.upper_idx[node];
+  cap = g.M;
+  return g.up_ids + ((size_t)ui * g.max_level + (layer - 1)) * g.M;
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam state in LDS.  res: sorted ascending array of keys (dist bits << 32 | slot << 1 | expanded)
+// == MinMaxHeap `res` (hnsw.rs:470) and, through the `expanded` bit, the part of the `candidates`
+// BinaryHeap (hnsw.rs:469) that can still be popped.  pool: candidates evicted from res whose
+// distance ties res.max (they are popped before in-res entries of equal distance because the
+// BinaryHeap pops the larger id first).  Entries evicted with a larger distance can never be
+// popped before the walk breaks and are dropped.
+// ---------------------------------------------------------------------------------------------
+struct Beam {
+  u64 *res;
+  u64 *pool;
+  int res_len, pool_len, rcap;
+  int n_weird;    // pool entries whose distance bits are not an ordinary non-negative float
+  u32 tie_bits;   // distance bits shared by the ordinary pool entries (== bits of res.max)
+  bool dropped;   // some evicted ordinary candidate with bits > res.max is still in `candidates`
+  u32 pool_over, err;
+};
+
+// OrderedFloat orders by bit pattern (ordered_float.rs:25-29) while the two raw compares in
+// walk_layer (hnsw.rs:485, 505) use float order.  They disagree only for sign-bit-set or NaN
+// distances ("weird": BQ-cosine has no clamp and gives -6e-8 for identical codes when
+// fl(sqrt(D))^2 < D).  Such entries sort last in every heap but never trigger the `f > f_max`
+// break, so evicted ones must stay poppable.
+__device__ __forceinline__ bool weird_bits(u32 b) { return b > 0x7F800000u; }
+
+__device__ __forceinline__ void pool_push(Beam &s, u64 key) {
+  if (s.pool_len < HNY_POOL_CAP) {
+    if (threadIdx.x == 0) s.pool[s.pool_len] = key & ~1ull;
+    s.pool_len++;
+    if (weird_bits((u32)(key >> 32))) s.n_weird++;
+    WSYNC();
+  } else {
+    s.pool_over++;
+  }
+}
+
+// res.max moved below the ordinary pool entries: they can never be popped before the break
+__device__ __forceinline__ void pool_drop_ties(Beam &s) {
+  if (s.pool_len - s.n_weird <= 0) return;
+  s.dropped = true;
+  if (s.n_weird == 0) {
+    s.pool_len = 0;
+    return;
+  }
+  const int ln = threadIdx.x;
+  u64 a0 = ln < s.pool_len ? s.pool[ln] : 0ull;
+  u64 a1 = ln + 64 < s.pool_len ? s.pool[ln + 64] : 0ull;
+  bool k0 = ln < s.pool_len && weird_bits((u32)(a0 >> 32));
+  bool k1 = ln + 64 < s.pool_len && weird_bits((u32)(a1 >> 32));
+  u64 m0 = __ballot(k0), m1 = __ballot(k1);
+  u64 lt = (1ull << ln) - 1ull;
+  WSYNC();
+  if (k0) s.pool[__popcll(m0 & lt)] = a0;
+  if (k1) s.pool[__popcll(m0) + __popcll(m1 & lt)] = a1;
+  s.pool_len = __popcll(m0) + __popcll(m1);
+  WSYNC();
+}
+
+// an entry leaves res (push_pop_max); nd = distance bits of the res.max that remains
+__device__ __forceinline__ void beam_evicted(Beam &s, u64 x, u32 nd) {
+  if (x & 1ull) return; // already popped from `candidates`
+  const u32 xb = (u32)(x >> 32);
+  if (weird_bits(xb)) {
+    pool_push(s, x);
+  } else if (xb == nd) {
+    s.tie_bits = nd;
+    pool_push(s, x);
+  } else {
+    s.dropped = true;
+  }
+}
+
+// res.push (len != ef) or res.push_pop_max (len == ef), hnsw.rs:508-512
+__device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
+  const int ln = threadIdx.x;
+  const int len = s.res_len;
+  int pos = 0;
+  for (int base = 0; base < len; base += 64) {
+    int e = base + ln;
+    bool lt = e < len && ((s.res[e] & ~1ull) < key);
+    pos += __popcll(__ballot(lt));
+  }
+  const bool evict = (len == ef);
+  const u64 oldmax = len ? s.res[len - 1] : 0ull;
+  if (evict && pos == len) { // the new entry is the max: pushed and popped at once
+    beam_evicted(s, key, (u32)(oldmax >> 32));
+    return;
+  }
+  if (!evict && len >= s.rcap) {
+    s.err = 1;
+    return;
+  }
+  const int hi = evict ? len - 1 : len; // entries [pos, hi) move up by one
+  if (hi > pos) {
+    for (int base = (hi - 1) & ~63; base >= (pos & ~63); base -= 64) {
+      int e = base + ln;
+      bool mv = e >= pos && e < hi;
+      u64 v = mv ? s.res[e] : 0ull;
+      WSYNC();
+      if (mv) s.res[e + 1] = v;
+      WSYNC();
+    }
+  }
+  if (ln == 0) s.res[pos] = key;
+  WSYNC();
+  if (!evict) {
+    s.res_len = len + 1;
+    return;
+  }
+  const u32 nd = (u32)(s.res[len - 1] >> 32);
+  if (s.pool_len - s.n_weird > 0 && s.tie_bits != nd) pool_drop_ties(s);
+  beam_evicted(s, oldmax, nd);
+}
+
+struct Visited {
+  u32 *bits;
+  u32 *vlog;
+  u32 bits_words, log_cap, log_len;
+  bool log_over;
+};
+
+__device__ __forceinline__ void visited_clear(Visited &v) {
+  const int ln = threadIdx.x;
+  if (v.log_over) {
+    for (u32 i = ln; i < v.bits_words; i += 64) v.bits[i] = 0u;
+  } else {
+    for (u32 i = ln; i < v.log_len; i += 64) v.bits[v.vlog[i] >> 5] = 0u;
+  }
+  v.log_len = 0;
+  v.log_over = false;
+  WSYNC();
+}
+
+// mark ids (one per lane, `valid` lanes) visited; returns whether this lane's id was new.
+__device__ __forceinline__ bool visited_insert(Visited &v, u32 id, bool valid) {
+  bool isnew = false;
+  if (valid) {
+    u32 b = 1u << (id & 31);
+    u32 old = atomicOr(&v.bits[id >> 5], b);
+    isnew = !(old & b);
+  }
+  return isnew;
+}
+
+__device__ __forceinline__ void visited_log(Visited &v, u32 id, bool isnew, u64 nmask, int rank) {
+  int n_new = __popcll(nmask);
+  if (v.log_len + n_new <= v.log_cap) {
+    if (isnew) v.vlog[v.log_len + rank] = id;
+  } else {
+    v.log_over = true;
+  }
+  v.log_len += n_new;
+}
+
+// One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
+template <int LPR, int NCH>
+__device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
+                               int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
+                               u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter) {
+  const int ln = threadIdx.x;
+  s.res_len = 0;
+  s.pool_len = 0;
+  s.n_weird = 0;
+  s.tie_bits = 0;
+  s.dropped = false;
+  // :474-481 every entry point goes to candidates and res (no capacity check) and is visited
+  {
+    u32 id = ln < n_eps ? eps[ln] : 0u;
+    bool isnew = visited_insert(vis, id, ln < n_eps);
+    u64 nmask = __ballot(isnew);
+    visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+    if (ln < n_eps) nb_ids[ln] = id;
+    WSYNC();
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_eps, nb_d);
+    evals += (u64)n_eps;
+    WSYNC();
+    for (int r = 0; r < n_eps; r++) {
+      u64 key = ((u64)fbits(nb_d[r]) << 32) | ((u64)nb_ids[r] << 1);
+      beam_insert(s, key, 0x7FFFFFFF);
+    }
+  }
+  for (u32 iter = 0;; iter++) {
+    if (iter > 200000u || s.err) {
+      if (iter > 200000u) err_iter = 1;
+      break;
+    }
+    // ---- candidates.peek()/pop(): smallest distance bits, larger id first among equals
+    // (BinaryHeap<(Reverse<OrderedFloat>, ItemId)>, :469, :483-488)
+    int first_un = -1;
+    for (int base = 0; base < s.res_len; base += 64) {
+      int e = base + ln;
+      bool un = e < s.res_len && !(s.res[e] & 1ull);
+      u64 mk = __ballot(un);
+      if (mk) {
+        first_un = base + __ffsll((long long)mk) - 1;
+        break;
+      }
+    }
+    const u32 dmax = (u32)(s.res[s.res_len - 1] >> 32);
+    // pop-order key: distance bits ascending, then id DESCENDING
+    u64 ta = ~0ull;
+    int last = first_un;
+    if (first_un >= 0) {
+      const u32 d0 = (u32)(s.res[first_un] >> 32);
+      for (int base = first_un & ~63; base < s.res_len; base += 64) {
+        int e = base + ln;
+        bool ok = e >= first_un && e < s.res_len && (u32)(s.res[e] >> 32) == d0 && !(s.res[e] & 1ull);
+        u64 mk = __ballot(ok);
+        if (mk) last = base + 63 - __clzll((long long)mk);
+        int ce = base + 63 < s.res_len - 1 ? base + 63 : s.res_len - 1;
+        if ((u32)(s.res[ce] >> 32) != d0) break;
+      }
+      ta = ((u64)d0 << 32) | (u64)(~(u32)(s.res[last] & 0xFFFFFFFEull));
+    }
+    u64 tp = ~0ull;
+    int pi = -1;
+    if (s.pool_len > 0) {
+      for (int e = ln; e < s.pool_len; e += 64) {
+        u64 k = s.pool[e];
+        u64 tk = (k & 0xFFFFFFFF00000000ull) | (u64)(~(u32)(k & 0xFFFFFFFFull));
+        if (pi < 0 || tk < tp) {
+          tp = tk;
+          pi = e;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        u64 ot = (u64)__shfl_xor((long long)tp, off, 64);
+        int oi = __shfl_xor(pi, off, 64);
+        if (oi >= 0 && (pi < 0 || ot < tp)) {
+          tp = ot;
+          pi = oi;
+        }
+      }
+    }
+    const bool have_a = first_un >= 0, have_p = pi >= 0;
+    if (!have_a && !have_p) break; // candidates exhausted (or only dropped entries: they break)
+    const bool use_pool = have_p && (!have_a || tp < ta);
+    const u32 fb = (u32)((use_pool ? tp : ta) >> 32);
+    // a dropped ordinary candidate precedes every weird one in pop order and breaks the walk
+    if (use_pool && weird_bits(fb) && s.dropped) break;
+    if (__uint_as_float(fb) > __uint_as_float(dmax)) break; // raw f32 compare, :485
+    u32 cslot;
+    if (use_pool) {
+      cslot = (~(u32)(tp & 0xFFFFFFFFull)) >> 1;
+      u64 lastk = s.pool[s.pool_len - 1];
+      WSYNC();
+      if (ln == 0) s.pool[pi] = lastk;
+      s.pool_len--;
+      if (weird_bits(fb)) s.n_weird--;
+      WSYNC();
+    } else {
+      cslot = (u32)(s.res[last] >> 1) & 0x7FFFFFFFu;
+      WSYNC();
+      if (ln == 0) s.res[last] |= 1ull;
+      WSYNC();
+    }
+    const float fmax = __uint_as_float(dmax); // f_max captured once per pop (:484)
+
+    // ---- neighbours of c (:491-495)
+    u32 cap;
+    const u32 *nl = nbr_ids(g, layer, cslot, cap);
+    u32 id = (u32)ln < cap ? nl[ln] : HNY_SENT;
+    bool valid = id != HNY_SENT;
+    bool isnew = visited_insert(vis, id, valid);
+    u64 nmask = __ballot(isnew);
+    if (!nmask) continue;
+    if (s.res_len < ef) {
+      // duplicates inside one list (add_link never dedups, hnsw.rs:521): while res is not full
+      // the order of acceptance matters, so the FIRST occurrence must be the one that counts
+      nb_ids[ln] = valid ? id : HNY_SENT;
+      WSYNC();
+      int firstj = ln;
+      bool anynew = isnew;
+      for (int j = 0; j < (int)cap; j++) {
+        u32 oj = nb_ids[j];
+        if (valid && oj == id) {
+          if (j < firstj) firstj = j;
+          if ((nmask >> j) & 1ull) anynew = true;
+        }
+      }
+      isnew = valid && anynew && firstj == ln;
+      WSYNC();
+      nmask = __ballot(isnew);
+    }
+    const int n_new = __popcll(nmask);
+    const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
+    visited_log(vis, id, isnew, nmask, rank);
+    if (isnew) nb_ids[rank] = id;
+    WSYNC();
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d); // :503
+    evals += (u64)n_new;
+    WSYNC();
+    const float myd = ln < n_new ? nb_d[ln] : 0.f;
+    const u32 myid = ln < n_new ? nb_ids[ln] : 0u;
+    int room = ef - s.res_len;
+    if (room < 0) room = 0;
+    // :505 `res.len() < ef || dist < f_max` — the first `room` new points are taken regardless
+    bool acc = ln < n_new && (ln < room || myd < fmax);
+    u64 amask = __ballot(acc);
+    WSYNC();
+    while (amask) {
+      int r = __ffsll((long long)amask) - 1;
+      amask &= amask - 1ull;
+      u32 db = fbits(__shfl(myd, r, 64));
+      u32 idr = (u32)__shfl((int)myid, r, 64);
+      beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
+    }
+  }
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64) void k_walk(GraphDev g, WalkArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *res = reinterpret_cast<u64 *>(smem);
+  u64 *pool = res + a.rcap;
+  u32 *nb_ids = reinterpret_cast<u32 *>(pool + HNY_POOL_CAP);
+  float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
+  u32 *eps = reinterpret_cast<u32 *>(nb_d + 64);
+  const int ln = threadIdx.x, t = ln % LPR;
+
+  Beam s;
+  s.res = res;
+  s.pool = pool;
+  s.rcap = (int)a.rcap;
+  s.pool_over = 0;
+  s.err = 0;
+  s.res_len = 0;
+  s.pool_len = 0;
+  s.n_weird = 0;
+  s.tie_bits = 0;
+  s.dropped = false;
+  Visited vis;
+  vis.bits = a.bits + (size_t)blockIdx.x * a.bits_words;
+  vis.vlog = a.vlog + (size_t)blockIdx.x * a.log_cap;
+  vis.bits_words = a.bits_words;
+  vis.log_cap = a.log_cap;
+  vis.log_len = 0;
+  vis.log_over = false;
+  u64 evals = 0;
+  u32 err_iter = 0, log_over_cnt = 0;
+
+  for (u32 m = a.lo + blockIdx.x; m < a.hi; m += gridDim.x) {
+    const unsigned char *qrow;
+    float qn = 0.f;
+    if (a.q_rows) {
+      qrow = a.q_rows + (size_t)m * a.q_stride;
+      if (a.q_norms) qn = a.q_norms[m];
+    } else {
+      u32 qslot = a.q_slots[m];
+      qrow = g.rows + (size_t)qslot * g.row_stride;
+      if (g.norms) qn = g.norms[qslot];
+    }
+    float4 q[NCH];
+    load_row<LPR, NCH>(qrow, t, g.n16, q);
+
+    int n_eps;
+    u32 start_layer;
+    if (a.first) { // :298 eps = all entry points
+      n_eps = (int)a.n_entry_points;
+      if (ln < n_eps) eps[ln] = a.entry_points[ln];
+      start_layer = g.max_level;
+    } else { // :316-321 eps = what was selected on the layer above
+      const u64 *sl = a.sel + (size_t)m * a.sel_stride +
+                      (size_t)(a.batch_level - (a.layer + 1)) * (a.cap_sel + 1);
+      n_eps = (int)sl[0];
+      if (ln < n_eps) eps[ln] = (u32)(sl[1 + ln] & 0xFFFFFFFFull);
+      start_layer = a.layer;
+    }
+    WSYNC();
+    for (u32 layer = start_layer;; layer--) {
+      const bool last = (layer == a.layer);
+      walk_one_layer<LPR, NCH>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+                               nb_d, evals, err_iter);
+      if (last) break;
+      // :305-306 eps = [closest]
+      if (ln == 0) eps[0] = (u32)(s.res[0] >> 1) & 0x7FFFFFFFu;
+      n_eps = 1;
+      // walk_layer owns a fresh visited set; Reader::hnsw_search shares `path` across the greedy
+      // layers and clears it once before layer 0 (reader.rs:731-743)
+      if (!a.reader_mode || layer == a.layer + 1) {
+        if (vis.log_over) log_over_cnt++;
+        visited_clear(vis);
+      }
+      WSYNC();
+    }
+    // result, ascending (res.into_vec() is re-sorted by robust_prune anyway, :573)
+    for (int e = ln; e < s.res_len; e += 64) {
+      u64 k = s.res[e];
+      a.cand[(size_t)m * a.rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+    }
+    if (ln == 0) a.cand_n[m] = (u32)s.res_len;
+    if (vis.log_over) log_over_cnt++;
+    visited_clear(vis);
+  }
+  if (ln == 0) {
+    if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
+    if (s.pool_over) atomicAdd(&g.stats[ST_POOL_OVERFLOW], (u64)s.pool_over);
+    if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
+    if (s.err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
+    if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// robust_prune (hnsw.rs:565-597) on a list that is already sorted ascending by (bits(d), id).
+// list/sel keys: dist bits << 32 | slot.  `exists i in S: bits(d(c,i)*alpha) < bits(dq)` does not
+// depend on evaluation order, so S is tested RPI rows at a time with an early exit per chunk.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__device__ int wave_prune(const GraphDev &g, const u64 *list, int n, int cap, u64 *S, u32 *s_ids,
+                          float *tmp_d, u64 &evals) {
+  constexpr int RPI = (64 / LPR) * RowsInFlight<NCH>::U;
+  const int ln = threadIdx.x, t = ln % LPR;
+  int s_len = 0;
+  for (int ci = 0; ci < n; ci++) {
+    if (s_len == cap) break; // :577-579
+    const u64 ck = list[ci];
+    const u32 cid = (u32)(ck & 0xFFFFFFFFull), cdb = (u32)(ck >> 32);
+    float4 c[NCH];
+    load_row<LPR, NCH>(g.rows + (size_t)cid * g.row_stride, t, g.n16, c);
+    float cn = g.norms ? g.norms[cid] : 0.f;
+    bool viol = false;
+    for (int k0 = 0; k0 < s_len && !viol; k0 += RPI) {
+      int cnt = s_len - k0 < RPI ? s_len - k0 : RPI;
+      dist_rows<LPR, NCH>(g, c, cn, s_ids + k0, cnt, tmp_d);
+      evals += (u64)cnt;
+      WSYNC();
+      bool v = false;
+      if (ln < cnt) {
+        float da = tmp_d[ln] * g.alpha; // :585 OrderedFloat(d * alpha) < dist_to_query
+        v = fbits(da) < cdb;
+      }
+      viol = __ballot(v) != 0ull;
+      WSYNC();
+    }
+    if (!viol) {
+      if (ln == 0) {
+        S[s_len] = ck;
+        s_ids[s_len] = cid;
+      }
+      s_len++;
+      WSYNC();
+    }
+  }
+  return s_len;
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64) void k_prune(GraphDev g, PruneArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *list = reinterpret_cast<u64 *>(smem);
+  u64 *S = list + a.rcap;
+  u32 *s_ids = reinterpret_cast<u32 *>(S + HNY_MAX_CAP);
+  float *tmp_d = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP);
+  const int ln = threadIdx.x;
+  u64 evals = 0;
+  for (u32 m = a.lo + blockIdx.x; m < a.hi; m += gridDim.x) {
+    int n = (int)a.cand_n[m];
+    for (int e = ln; e < n; e += 64) list[e] = a.cand[(size_t)m * a.rcap + e];
+    WSYNC();
+    int s_len = wave_prune<LPR, NCH>(g, list, n, (int)a.cap, S, s_ids, tmp_d, evals);
+    u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
+    if (ln == 0) out[0] = (u64)s_len;
+    if (ln < s_len) out[1 + ln] = S[ln];
+    WSYNC();
+  }
+  if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_PRUNE], evals);
+}
+
+// ---------------------------------------------------------------------------------------------
+// link ops.  For batch member m (in batch order), layer l from its level down to 0, k-th selected
+// (d, n): LINK(q,(d,n),l) then LINK(n,(d,q),l) (hnsw.rs:316-324).  key = layer:3 | target:31 |
+// seq:30 — a full 64-bit sort groups ops by target and keeps the reference's sequential order
+// inside each target; ops on different targets commute.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_emit(GraphDev g, EmitArgs a) {
+  const u32 n_layers = a.batch_level + 1;
+  const u64 total = (u64)a.count * n_layers * a.cap_sel;
+  u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  u32 k = (u32)(idx % a.cap_sel);
+  u32 li = (u32)((idx / a.cap_sel) % n_layers);
+  u32 m = (u32)(idx / ((u64)a.cap_sel * n_layers));
+  const u64 *s = a.sel + (size_t)m * a.sel_stride + (size_t)li * (a.cap_sel + 1);
+  u64 o = idx * 2;
+  if (k < (u32)s[0]) {
+    u64 e = s[1 + k];
+    u64 nb = e & 0xFFFFFFFFull, db = e >> 32;
+    u64 q = a.q_slots[m];
+    u64 layer = (u64)(a.batch_level - li);
+    a.keys[o] = (layer << 61) | (q << 30) | o;
+    a.vals[o] = (db << 32) | nb;
+    a.keys[o + 1] = (layer << 61) | (nb << 30) | (o + 1);
+    a.vals[o + 1] = (db << 32) | q;
+    atomicAdd(&g.stats[ST_LINKS], 2ull); // build_stats.incr_link_count(2), hnsw.rs:323
+  } else {
+    a.keys[o] = HNY_OP_INVALID;
+    a.keys[o + 1] = HNY_OP_INVALID;
+  }
+}
+
+__global__ void k_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ops) return;
+  u64 k = keys[i];
+  if (k == HNY_OP_INVALID) return;
+  if (i == 0 || (keys[i - 1] >> 30) != (k >> 30)) seg_start[atomicAdd(n_seg, 1u)] = i;
+}
+
+// add_link (hnsw.rs:523-560) for every op of one (layer, target), in order.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
+  __shared__ u64 lk[HNY_MAX_CAP];     // the node's list: dist bits << 32 | slot
+  __shared__ u64 sorted[HNY_MAX_CAP];
+  __shared__ u64 S[HNY_MAX_CAP];
+  __shared__ u32 s_ids[HNY_MAX_CAP];
+  __shared__ float tmp_d[HNY_MAX_CAP];
+  const int ln = threadIdx.x;
+  const u32 n_seg = *a.n_seg;
+  u64 evals = 0;
+  for (u32 sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
+    const u32 i0 = a.seg_start[sg];
+    const u64 k0 = a.keys[i0] >> 30;
+    const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
+    u32 cap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)target * g.M0;
+      dist = g.l0_dist + (size_t)target * g.M0;
+      cntp = g.l0_cnt + target;
+    } else { // :534 `layers.get(level)` — the target always has this layer (it was found on it)
+      size_t u = (size_t)g.upper_idx[target] * g.max_level + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    u32 cw = *cntp;
+    int cnt = (int)(cw & 0xFFFFu);
+    bool frozen = (cw >> 31) != 0u;
+    if (ln < cnt) lk[ln] = ((u64)fbits(dist[ln]) << 32) | ids[ln];
+    WSYNC();
+    for (u32 i = i0; i < a.n_ops; i++) {
+      const u64 key = a.keys[i];
+      if (key == HNY_OP_INVALID || (key >> 30) != k0) break;
+      const u64 val = a.vals[i];
+      if ((u32)(val & 0xFFFFFFFFull) == target) continue; // :530 p == q.1
+      if (cnt < (int)cap) {                               // :542-545 append, no dedup
+        if (ln == 0) lk[cnt] = val;
+        cnt++;
+        WSYNC();
+      } else if (!frozen) { // :547-552 full: self-prune, the new link is dropped
+        u64 mine = ln < cnt ? lk[ln] : 0ull;
+        int rk = 0;
+        for (int j = 0; j < cnt; j++) {
+          u64 o = lk[j];
+          rk += (o < mine || (o == mine && j < ln)) ? 1 : 0;
+        }
+        if (ln < cnt) sorted[rk] = mine;
+        WSYNC();
+        int s_len = wave_prune<LPR, NCH>(g, sorted, cnt, (int)cap, S, s_ids, tmp_d, evals);
+        if (ln < s_len) lk[ln] = S[ln];
+        cnt = s_len;
+        // a full list that prunes to itself can never change again: every later add_link would
+        // redo the same prune with the same outcome
+        frozen = (s_len == (int)cap);
+        WSYNC();
+      }
+    }
+    if ((u32)ln < cap) {
+      bool on = ln < cnt;
+      ids[ln] = on ? (u32)(lk[ln] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[ln] = on ? __uint_as_float((u32)(lk[ln] >> 32)) : 0.f;
+    }
+    if (ln == 0) *cntp = (u32)cnt | (frozen ? 0x80000000u : 0u);
+    WSYNC();
+  }
+  if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
+}
+
+// D::distance for explicit pairs of stored items (tests / parity checks)
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64) void k_pair_distances(GraphDev g, const u32 *pa, const u32 *pb, u32 n,
+                                                       float *out) {
+  __shared__ u32 ids[64];
+  __shared__ float d[64];
+  const int ln = threadIdx.x, t = ln % LPR;
+  for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+    u32 qa = pa[i];
+    float4 q[NCH];
+    load_row<LPR, NCH>(g.rows + (size_t)qa * g.row_stride, t, g.n16, q);
+    float qn = g.norms ? g.norms[qa] : 0.f;
+    if (ln == 0) ids[0] = pb[i];
+    WSYNC();
+    dist_rows<LPR, NCH>(g, q, qn, ids, 1, d);
+    WSYNC();
+    if (ln == 0) out[i] = d[0];
+    WSYNC();
+  }
+}
+
+__global__ void k_fill_u32(u32 *p, u32 v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+template <template <int, int> class Launcher, typename... Args>
+hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
+#define HNY_CASE(L, C) \
+  if (s.lpr == L && s.nch == C) return Launcher<L, C>::run(args...);
+  HNY_CASE(8, 1)
+  HNY_CASE(16, 1)
+  HNY_CASE(32, 1)
+  HNY_CASE(64, 1)
+  HNY_CASE(64, 2)
+  HNY_CASE(64, 3)
+  HNY_CASE(64, 4)
+  HNY_CASE(64, 6)
+  HNY_CASE(64, 8)
+#undef HNY_CASE
+  return hipErrorInvalidValue;
+}
+
+template <int L, int C>
+struct WalkLauncher {
+  static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
+    size_t lds = hnyk_walk_lds_bytes(a.rcap);
+    hipLaunchKernelGGL((k_walk<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
+struct PruneLauncher {
+  static hipError_t run(const GraphDev &g, const PruneArgs &a, int grid, hipStream_t st) {
+    size_t lds = (size_t)a.rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4);
+    hipLaunchKernelGGL((k_prune<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
+struct ApplyLauncher {
+  static hipError_t run(const GraphDev &g, const ApplyArgs &a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_apply<L, C>), dim3(grid), dim3(64), 0, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
+struct PairLauncher {
+  static hipError_t run(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
+                        hipStream_t st) {
+    int grid = n < 4096u ? (int)n : 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_pair_distances<L, C>), dim3(grid), dim3(64), 0, st, g, a, b, n, out);
+    return hipGetLastError();
+  }
+};
+
+} // namespace
+
+size_t hnyk_walk_lds_bytes(u32 rcap) {
+  return (size_t)rcap * 8 + HNY_POOL_CAP * 8 + 64 * 4 * 2 + HNY_MAX_EPS * 4;
+}
+
+hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<WalkLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<PruneLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<ApplyLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
+                               LaunchShape s, hipStream_t st) {
+  return dispatch_shape<PairLauncher>(s, g, a, b, n, out, st);
+}
+hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st) {
+  u64 total = (u64)a.count * (a.batch_level + 1) * a.cap_sel;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, a);
+  return hipGetLastError();
+}
+hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st) {
+  if (!n_ops) return hipSuccess;
+  hipLaunchKernelGGL(k_segments, dim3((n_ops + 255) / 256), dim3(256), 0, st, keys, n_ops, seg_start,
+                     n_seg);
+  return hipGetLastError();
+}
+hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, st, p, v, n);
+  return hipGetLastError();
+}
+hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
+                           u64 *vals_out, u32 n, hipStream_t st) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
+                                   0, 64, st);
+}

@@ -1,0 +1,161 @@
+/*
+ * hannoy_amd.h — C ABI of the MI355X-native HNSW index builder for hannoy.
+ *
+ * Drop-in boundary: the reference has no FFI for the build; the seam is inside
+ * HnswBuilder::build (/root/reference/src/hnsw.rs:122-216) between "inputs read through
+ * FrozenReader" (hnsw.rs:138, src/parallel.rs:33-45) and the single-threaded LMDB write loop
+ * (hnsw.rs:191-213).  A maintainer replaces the body of HnswBuilder::build with: export items →
+ * hny_build() → for each record db.put(Key::links(..), Links) (INTEGRATION.md shows the Rust
+ * binding).  All pointers are caller-owned unless stated; the library never frees caller memory.
+ * Plain C types only.  One host thread drives one builder (same contract as Writer::build, which
+ * takes &mut RwTxn, /root/reference/src/writer.rs:521).
+ *
+ * The library REQUIRES a gfx950 GPU: there is no CPU fallback; every entry point that computes
+ * returns HNY_ERR_NO_DEVICE when no device is usable.
+ */
+#ifndef HANNOY_AMD_H
+#define HANNOY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces: trait Distance implementors, src/distance/mod.rs:3-10 (names: cosine.rs:32-34 etc.) */
+typedef enum {
+  HNY_COSINE = 0,
+  HNY_EUCLIDEAN = 1,
+  HNY_MANHATTAN = 2,
+  HNY_HAMMING = 3,
+  HNY_BQ_COSINE = 4,
+  HNY_BQ_EUCLIDEAN = 5,
+  HNY_BQ_MANHATTAN = 6
+} hny_metric;
+
+/* error codes; mirror of the variants the build can surface (src/error.rs:10-87) */
+enum {
+  HNY_OK = 0,
+  HNY_ERR_INVALID_ARG = -1,      /* null pointer, M0 < M, unsorted ids, ... */
+  HNY_ERR_CANCELLED = -2,        /* Error::BuildCancelled, error.rs:58-59 */
+  HNY_ERR_MISSING_KEY = -3,      /* Error::MissingKey, error.rs:61-72 (entry point not in items) */
+  HNY_ERR_INVALID_DIM = -4,      /* Error::InvalidVecDimension, error.rs:19-26 (stride/dim mismatch) */
+  HNY_ERR_UNSUPPORTED = -5,      /* dim / M0 / ef beyond what the kernels are built for */
+  HNY_ERR_NO_DEVICE = -6,        /* no usable gfx950 device / HIP failure */
+  HNY_ERR_DEVICE = -7,           /* a kernel reported an internal overflow (see hny_last_error) */
+  HNY_ERR_OOM = -8
+};
+
+/* replaces: BuildOption + const generics M, M0 (src/writer.rs:34-58, 215-220) + rng (hnsw.rs:129) */
+typedef struct {
+  int32_t metric;            /* hny_metric */
+  uint32_t dim;              /* user dimensions (binary codecs pad to 64, binary.rs:80-94) */
+  uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120) */
+  uint32_t ef_construction;  /* default 100 (writer.rs:49) */
+  float alpha;               /* default 1.0 (writer.rs:51) */
+  uint64_t seed;             /* level RNG seed when items.levels == NULL */
+  int (*cancel)(void *);     /* polled between batches, at least every 10 000 items (lib.rs:140) */
+  void *cancel_ctx;
+  void (*progress)(void *, uint64_t done, uint64_t total); /* progress.rs:3-16 */
+  void *progress_ctx;
+  /* batch-synchronous insertion schedule: batch = clamp(floor(batch_frac * n_inserted), 1,
+   * batch_max).  batch_max = 1 reproduces strictly sequential insertion (the reference with one
+   * rayon thread, src/tests/mod.rs:105).  0 / 0.0 select the defaults. */
+  double batch_frac;
+  uint32_t batch_max;
+  int32_t device;            /* HIP device ordinal; -1 = current */
+} hny_build_opts;
+
+/* replaces: what FrozenReader hands to the builder (src/parallel.rs:33-45) */
+typedef struct {
+  uint64_t n;
+  const uint32_t *ids;       /* strictly ascending (RoaringBitmap order, hnsw.rs:142-144) */
+  const void *vectors;       /* codec bytes exactly as stored after the header (node.rs:136-140) */
+  size_t stride;             /* bytes between vectors; >= codec size */
+  const void *headers;       /* D::Header bytes: f32 norm | f32 bias | u64 idx (hamming.rs:21-25) */
+  size_t header_size;        /* 4 or 8 */
+  const uint8_t *levels;     /* optional: inject levels instead of drawing them from `seed` */
+} hny_items;
+
+/* replaces: what the write loop consumes (hnsw.rs:195-213) + entry_points/max_level read back by
+ * Writer::build (writer.rs:591-592) + BuildStats (stats.rs:10-19).  Library-owned. */
+typedef struct {
+  uint64_t n_records;        /* one per (item, layer) key, sorted by (item id, layer) */
+  const uint32_t *rec_item;  /* item id */
+  const uint8_t *rec_layer;
+  const uint64_t *rec_offset; /* n_records + 1 offsets into neighbours */
+  const uint32_t *neighbours; /* item ids, ascending, deduplicated (RoaringBitmap::from_iter) */
+  const uint32_t *entry_points;
+  uint32_t n_entry_points;
+  uint32_t max_level;
+  uint64_t n_links_added;     /* BuildStats.n_links_added */
+  uint64_t n_distance_evals;  /* distance evaluations performed on the device */
+  uint64_t n_evals_walk, n_evals_prune, n_evals_apply;
+  uint64_t n_batches;
+  double t_upload_s, t_build_s, t_export_s; /* host wall clock of the three phases */
+  uint64_t n_tie_pool_overflow; /* exactness counter, 0 in every supported case */
+} hny_graph;
+
+typedef struct hny_builder hny_builder;
+
+typedef struct {
+  uint64_t first;  /* index of the batch's first member in insertion order */
+  uint32_t count;  /* 0 = build finished */
+  uint32_t level;  /* level shared by every member (batches never straddle level groups) */
+  uint32_t n_layers; /* level + 1 */
+  uint32_t sel_stride_u64; /* u64 words per member in a selection buffer */
+} hny_batch;
+
+/* ---- one-call build: replaces HnswBuilder::build (hnsw.rs:122-216) ---- */
+int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **out);
+void hny_graph_free(hny_graph *g);
+
+/* ---- stepwise build (what hny_build loops over; used by the multi-GPU driver) ---- */
+int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out);
+int hny_builder_reset(hny_builder *b); /* empty graph again, vectors stay resident in HBM */
+int hny_builder_next_batch(hny_builder *b, hny_batch *out);
+/* search + prune (walk_layer hnsw.rs:460-518, robust_prune :565-597) for members [lo, hi) of the
+ * current batch against the frozen graph; results go to sel_dev (device memory, count *
+ * sel_stride_u64 u64 words for the WHOLE batch; NULL = internal buffer) */
+int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev);
+/* add_link for every selected pair, both directions (hnsw.rs:316-324, 523-560), in batch order */
+int hny_builder_apply(hny_builder *b, const void *sel_dev);
+int hny_builder_sync(hny_builder *b);
+int hny_builder_finish(hny_builder *b, hny_graph **out);
+void hny_builder_destroy(hny_builder *b);
+/* the schedule: batch size when n_done items are already inserted */
+uint32_t hny_batch_size(double batch_frac, uint32_t batch_max, uint64_t n_done);
+
+/* ---- distances (trait Distance::distance, src/distance/mod.rs:41): pairs of stored items ---- */
+int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot_a,
+                          const uint32_t *slot_b, float *out);
+
+/* ---- search: Reader::nns().by_vector (src/reader.rs:132-148, 642-665, 722-800) on the graph
+ * held by the builder (after the build, before destroy).  Queries are codec bytes + headers. */
+int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvectors, size_t qstride,
+                           const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
+                           float *out_dists, uint32_t *out_counts);
+
+/* ---- codecs: UnalignedVectorCodec::from_slice (src/unaligned_vector/{f32,binary,
+ * binary_quantized}.rs) + Distance::new_header (cosine.rs:36-38 ...) ---- */
+size_t hny_vector_bytes(int32_t metric, uint32_t dim);
+size_t hny_header_bytes(int32_t metric);
+int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
+                       void *out_codes, void *out_headers);
+
+/* ---- on-disk records (key.rs:54-82, node.rs:130-174, metadata.rs:22-73, version.rs:33-60) ---- */
+typedef int (*hny_kv_sink)(void *ctx, const uint8_t *key, size_t key_len, const uint8_t *val,
+                           size_t val_len);
+/* emits, in LMDB key order, exactly the records Writer::build leaves behind for a fresh index:
+ * Metadata, Version, every Links record, and (with_items) every Item record */
+int hny_encode_kv(const hny_graph *g, const hny_build_opts *opts, const hny_items *items,
+                  uint16_t index, int with_items, hny_kv_sink sink, void *ctx);
+
+const char *hny_last_error(void);
+const char *hny_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -245,15 +245,26 @@ inline uint32_t wave_lpr(uint32_t dim) {
   return l;
 }
 enum { WOP_DOT = 0, WOP_EUCLID = 1, WOP_MANHATTAN = 2 };
+/* chunks per lane, rounded up to the kernel's template set {1,2,3,4,6,8} */
+inline uint32_t wave_nch(uint32_t dim4, uint32_t lpr) {
+  uint32_t n = (dim4 + lpr - 1) / lpr;
+  static const uint32_t set[] = {1, 2, 3, 4, 6, 8};
+  for (uint32_t s : set)
+    if (n <= s) return s;
+  return n;
+}
+/* Lane t of an LPR-lane group owns float4 #(c*LPR + t) of the (zero padded) row for c < NCH and
+ * runs ONE fma chain over its 4*NCH elements in index order; the LPR partials are then combined
+ * with an xor butterfly, offsets LPR/2 ... 1.  (hannoy_amd/csrc/hny_kernels.hip: row_partial,
+ * butterfly_f32) */
 float wave_reduce(int op, const void *a, const void *b, uint32_t dim) {
   uint32_t dim4 = (dim + 3) / 4, lpr = wave_lpr(dim);
-  uint32_t nch = (dim4 + lpr - 1) / lpr;
+  uint32_t nch = wave_nch(dim4, lpr);
   float v[64];
   for (uint32_t t = 0; t < lpr; t++) {
     float acc = 0.0f;
     for (uint32_t c = 0; c < nch; c++) {
       uint32_t f = c * lpr + t;
-      if (f >= dim4) continue;
       for (uint32_t j = 0; j < 4; j++) {
         uint32_t e = 4 * f + j;
         float x = e < dim ? loadf(a, e) : 0.0f, y = e < dim ? loadf(b, e) : 0.0f;

@@ -1,0 +1,99 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, same seeded inputs."""
+import numpy as np
+import pytest
+
+from conftest import draw_levels
+
+pytestmark = pytest.mark.gpu
+
+METRICS = {"cosine": 0, "euclidean": 1, "manhattan": 2, "hamming": 3}
+
+
+@pytest.fixture(scope="module")
+def hny():
+    import hannoy_amd
+    hannoy_amd.load_library()
+    return hannoy_amd
+
+
+def _mk(orc, hny, metric, vecs, levels):
+    ds = orc.Dataset.from_f32(metric, vecs, levels)
+    items = hny.ItemSet(metric, vecs.shape[1], ds.ids, ds.codes, ds.headers, ds.levels)
+    return ds, items
+
+
+def _same_graph(g, o):
+    assert g.entry_points.tolist() == o.entry_points.tolist()
+    assert g.max_level == o.max_level
+    assert np.array_equal(g.rec_item, o.rec_item)
+    assert np.array_equal(g.rec_layer, o.rec_layer)
+    assert np.array_equal(g.offsets, o.offsets)
+    assert np.array_equal(g.nbrs, o.nbrs)
+
+
+def test_kat1_on_gpu(kat, orc, hny):
+    k = kat["kat1"]
+    v = np.array(k["vectors"], np.float32)
+    ds, items = _mk(orc, hny, 1, v, k["levels"])
+    g = hny.build(items, M=3, M0=3, ef_construction=100, batch_max=1)
+    assert g.entry_points.tolist() == k["entry_points"] and g.max_level == k["max_level"]
+    assert [[i, l, nb] for (i, l), nb in sorted(g.as_dict().items())] == k["links"]
+
+
+@pytest.mark.parametrize("metric,dim", [(0, 768), (1, 768), (2, 96), (0, 128), (1, 3), (0, 20),
+                                        (3, 1024), (4, 256), (5, 100), (6, 64), (0, 1536)])
+def test_pair_distances_bit_exact_wave_order(orc, hny, metric, dim):
+    rng = np.random.default_rng(100 + metric * 7 + dim)
+    n = 300
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    lv = np.zeros(n, np.uint8)
+    lv[0] = 1
+    ds, items = _mk(orc, hny, metric, vecs, lv)
+    with hny.Builder(items, M=4, M0=8) as b:
+        a = rng.integers(0, n, 2000).astype(np.uint32)
+        c = rng.integers(0, n, 2000).astype(np.uint32)
+        got = b.distances(a, c)
+    want_wave = np.array([orc.distance(metric, orc.ORDER_WAVE, dim, ds.codes[i], ds.headers[i],
+                                       ds.codes[j], ds.headers[j]) for i, j in zip(a, c)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want_wave.view(np.uint32))
+    # against the reference's own x86 order: integer metrics bit-exact, f32 within 1e-5 relative
+    want_x86 = np.array([orc.distance(metric, orc.ORDER_X86, dim, ds.codes[i], ds.headers[i],
+                                      ds.codes[j], ds.headers[j]) for i, j in zip(a, c)], np.float32)
+    if metric >= 3:
+        assert np.array_equal(got.view(np.uint32), want_x86.view(np.uint32))
+    elif metric == 0:
+        assert np.max(np.abs(got - want_x86)) <= 1e-6  # (1-cos)/2: absolute bound
+    else:
+        assert np.max(np.abs(got - want_x86) / np.maximum(want_x86, 1e-30)) <= 1e-5
+
+
+CASES = [
+    # metric, n, dim, M, M0, ef, frac, bmax
+    (1, 200, 16, 3, 3, 20, 0.0, 1),
+    (0, 500, 32, 4, 8, 24, 0.0, 1),
+    (0, 2000, 64, 8, 16, 48, 0.05, 64),
+    (1, 3000, 128, 16, 32, 100, 0.02, 256),
+    (0, 4000, 768, 16, 32, 100, 0.05, 512),
+    (2, 1500, 48, 6, 12, 32, 0.1, 128),
+    (3, 3000, 256, 8, 16, 32, 0.05, 128),
+    (4, 2000, 512, 8, 16, 32, 0.05, 128),
+    (5, 1000, 100, 6, 6, 16, 0.05, 64),
+    (6, 1000, 64, 6, 6, 16, 0.05, 64),
+    (1, 2500, 100, 32, 64, 200, 0.05, 256),
+]
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,frac,bmax", CASES)
+def test_build_equals_oracle_bit_exact(orc, hny, metric, n, dim, M, M0, ef, frac, bmax):
+    """Same schedule, same summation order -> the GPU graph must equal the oracle's edge for edge."""
+    rng = np.random.default_rng(7 * n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    if metric >= 3:  # make ties/duplicates likely for the integer metrics
+        vecs[rng.integers(0, n, n // 20)] = vecs[rng.integers(0, n, n // 20)]
+    levels = draw_levels(n, M, seed=n + dim)
+    ds, items = _mk(orc, hny, metric, vecs, levels)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+    assert g.n_tie_pool_overflow == 0
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added
