@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: HNSW build throughput (vectors indexed / s) + recall@10.
+
+Workload (BASELINE.json configs[1], "C2"): 1M x 768 f32 Cosine, M=16 (M0=32), ef_construction=100,
+one MI355X, vectors resident in HBM before the timed region.  One "step" = one complete build of
+the index (graph reset -> every batch searched, pruned, linked -> records exported to the host).
+
+  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) carrying `roofline`
+(dominant kernel = k_walk, HIP events on the build stream) and `cpu_baseline` (the CPU oracle, i.e.
+a port of the reference algorithm — the real hannoy crate cannot be built here: no Rust, no LMDB).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=1_000_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--metric", default="cosine", choices=["cosine", "euclidean", "manhattan", "hamming"])
+    p.add_argument("--M", type=int, default=16)
+    p.add_argument("--M0", type=int, default=0)
+    p.add_argument("--ef", type=int, default=100)
+    p.add_argument("--data", default="clustered", choices=["clustered", "uniform"])
+    p.add_argument("--batch-frac", type=float, default=0.0)
+    p.add_argument("--batch-max", type=int, default=0)
+    p.add_argument("--queries", type=int, default=1000)
+    p.add_argument("--ef-search", type=int, default=100)
+    p.add_argument("--cpu-sample", type=int, default=20000)
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-recall", action="store_true")
+    p.add_argument("--seed", type=int, default=42)
+    return p.parse_args()
+
+
+def gen_data(torch, n, dim, kind, seed, device):
+    """Synthetic vectors, generated on the GPU (counter-based Philox -> identical on every rank)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if kind == "uniform":  # reference-style U(-1,1) (src/tests/mod.rs:133-136)
+        x = torch.rand((n, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1
+    else:  # 1024-centre Gaussian mixture, centres U(-1,1), sigma 0.15
+        centres = torch.rand((1024, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1
+        which = torch.randint(0, 1024, (n,), generator=g, device=device)
+        x = centres[which] + 0.15 * torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    return x
+
+
+def brute_force_topk(torch, metric, data, queries, k):
+    """Exact top-k under the reference's metric definition (plumbing, torch on the GPU)."""
+    out = []
+    for q0 in range(0, queries.shape[0], 256):
+        q = queries[q0:q0 + 256]
+        if metric == "cosine":
+            s = (q / q.norm(dim=1, keepdim=True)) @ (data / data.norm(dim=1, keepdim=True)).T
+            out.append(torch.topk(s, k, dim=1).indices)
+        elif metric == "euclidean":
+            d = torch.cdist(q, data)
+            out.append(torch.topk(d, k, dim=1, largest=False).indices)
+        elif metric == "manhattan":
+            d = torch.cdist(q, data, p=1)
+            out.append(torch.topk(d, k, dim=1, largest=False).indices)
+        else:  # hamming on the Binary codec bits (x > 0)
+            qb, db = (q > 0).float(), (data > 0).float()
+            d = qb @ (1 - db).T + (1 - qb) @ db.T
+            out.append(torch.topk(d, k, dim=1, largest=False).indices)
+    return torch.cat(out).cpu().numpy()
+
+
+def recall_at_k(found, counts, truth):
+    hit = 0
+    for i in range(truth.shape[0]):
+        hit += len(set(found[i, :counts[i]].tolist()) & set(truth[i].tolist()))
+    return hit / truth.size
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import hannoy_amd as H
+    from hannoy_amd import multigpu
+    H.load_library()
+    metric = {"cosine": H.COSINE, "euclidean": H.EUCLIDEAN, "manhattan": H.MANHATTAN,
+              "hamming": H.HAMMING}[a.metric]
+    M0 = a.M0 or 2 * a.M
+
+    # ---- synthetic data (+ held-out queries from the same distribution) ----
+    x_dev = gen_data(torch, a.n, a.dim, a.data, a.seed, dev)
+    q_dev = gen_data(torch, a.queries, a.dim, a.data, a.seed + 1000, dev) if a.queries else None
+    if a.data == "clustered" and a.queries:  # queries: fresh noise around the SAME centres
+        g = torch.Generator(device=dev)
+        g.manual_seed(a.seed)
+        centres = torch.rand((1024, a.dim), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(a.seed + 1000)
+        which = torch.randint(0, 1024, (a.queries,), generator=g2, device=dev)
+        q_dev = centres[which] + 0.15 * torch.randn((a.queries, a.dim), generator=g2, device=dev)
+    x = x_dev.cpu().numpy()
+    items = H.ItemSet.from_f32(metric, x)
+    row_bytes = items.codes.shape[1]
+    bytes_per_eval = row_bytes + items.headers.shape[1]  # row + header
+
+    builder = H.Builder(items, M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed,
+                        batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank)
+    builder.set_profiling(True)
+    driver = multigpu.Driver(builder, torch, dist if world > 1 else None, rank, world, dev)
+
+    def step():
+        builder.reset()
+        driver.run()
+        return builder.finish()
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    graph = None
+    for _ in range(a.steps):
+        graph = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if graph is None:
+        graph = step()
+    value = a.n * a.steps / dt if a.steps else 0.0
+
+    # ---- roofline of the dominant kernel (k_walk): algorithmic bytes / device time ----
+    walk_bytes = graph.n_evals_walk * bytes_per_eval
+    roof = None
+    if graph.t_walk_kernels_s > 0:
+        ach = walk_bytes / graph.t_walk_kernels_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_walk",
+                "launches": int(graph.n_walk_launches),
+                "avg_launch_ms": round(1e3 * graph.t_walk_kernels_s / max(1, graph.n_walk_launches), 4),
+                "algorithmic_bytes_per_launch": int(walk_bytes / max(1, graph.n_walk_launches)),
+                "bytes_per_eval": bytes_per_eval}
+
+    out = {
+        "metric": "vectors indexed/sec (build) + recall@10, 1M x 768 Cosine M=16 efC=100",
+        "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(1e3 * dt / max(1, a.steps), 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if metric < H.HAMMING else "u64-popcount", "data": "synthetic",
+        "config": {"workload": f"C2: {a.n} x {a.dim} {a.metric}, M={a.M} M0={M0} efC={a.ef}, "
+                               f"{a.data} synthetic vectors resident in HBM, 1 step = 1 full build",
+                   "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
+                   "batch_frac": builder.opts.batch_frac or 0.02,
+                   "batch_max": builder.opts.batch_max or 16384,
+                   "parallelism": f"item-sharded search x{world}, replicated graph"},
+        "roofline": roof,
+        "build": {"n_batches": int(graph.n_batches), "n_distance_evals": int(graph.n_distance_evals),
+                  "evals_walk": int(graph.n_evals_walk), "evals_prune": int(graph.n_evals_prune),
+                  "evals_apply": int(graph.n_evals_apply), "links_added": int(graph.n_links_added),
+                  "t_build_s": round(graph.t_build_s, 3), "t_export_s": round(graph.t_export_s, 3),
+                  "t_upload_s": round(graph.t_upload_s, 3),
+                  "t_walk_kernels_s": round(graph.t_walk_kernels_s, 3),
+                  "t_prune_kernels_s": round(graph.t_prune_kernels_s, 3),
+                  "t_sort_kernels_s": round(graph.t_sort_kernels_s, 3),
+                  "t_apply_kernels_s": round(graph.t_apply_kernels_s, 3),
+                  "tie_pool_overflow": int(graph.n_tie_pool_overflow)},
+    }
+
+    if rank == 0 and not a.no_recall and a.queries:
+        truth = brute_force_topk(torch, a.metric, x_dev, q_dev, 10)
+        qc, qh = H.encode_vectors(metric, q_dev.cpu().numpy())
+        t1 = time.perf_counter()
+        ids, dists, counts = builder.search_knn(qc, qh, k=10, ef_search=a.ef_search)
+        ts = time.perf_counter() - t1
+        out["recall_at_10"] = round(recall_at_k(ids, counts, truth), 4)
+        out["search"] = {"queries": a.queries, "ef_search": a.ef_search,
+                         "qps_incl_transfers": round(a.queries / ts, 1)}
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle = port of the reference algorithm ----
+    if rank == 0 and world == 1 and not a.no_cpu and a.cpu_sample > 0:
+        from oracle import orc
+        from tests.conftest import draw_levels
+        ns = min(a.cpu_sample, a.n)
+        cores = os.cpu_count() or 1
+        lv = draw_levels(ns, a.M, a.seed)
+        ds = orc.Dataset(metric, a.dim, np.arange(ns, dtype=np.uint32), items.codes[:ns],
+                         items.headers[:ns], lv)
+        t1 = time.perf_counter()
+        og = orc.build(ds, M=a.M, M0=M0, ef=a.ef, order=orc.ORDER_X86, threads=cores)
+        tc = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": round(ns / tc, 1), "unit": "vectors/s", "cores": cores, "kind": "port",
+            "sample": f"first {ns} of the {a.n} vectors, same params, vectors in RAM, "
+                      f"{cores} threads (rayon-like), AVX2+FMA kernels; a smaller index is cheaper "
+                      f"per insert than the 1M one, so this flatters the CPU",
+            "seconds": round(tc, 2)}
+        # recall parity on the sample: CPU-built vs GPU-built graph, both searched by the oracle
+        if not a.no_recall and a.queries:
+            sub = H.ItemSet(metric, a.dim, ds.ids, ds.codes, ds.headers, lv)
+            gg = H.build(sub, M=a.M, M0=M0, ef_construction=a.ef, batch_frac=a.batch_frac,
+                         batch_max=a.batch_max, device=local_rank)
+            truth_s = brute_force_topk(torch, a.metric, x_dev[:ns], q_dev, 10)
+            r_cpu = recall_at_k(*orc.search(ds, og, qc, qh, k=10, ef_search=a.ef_search,
+                                            threads=cores)[0::2], truth_s)
+            r_gpu = recall_at_k(*orc.search(ds, gg, qc, qh, k=10, ef_search=a.ef_search,
+                                            threads=cores)[0::2], truth_s)
+            out["recall_parity_on_sample"] = {"n": ns, "cpu_built": round(r_cpu, 4),
+                                              "gpu_built": round(r_gpu, 4)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    builder.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,7 @@ ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_DEVICE, ERR_OOM = -5, -6, -7, -8
 EXPORTED = [
     "hny_build", "hny_graph_free", "hny_builder_create", "hny_builder_reset",
     "hny_builder_next_batch", "hny_builder_search", "hny_builder_apply", "hny_builder_sync",
-    "hny_builder_finish", "hny_builder_destroy", "hny_batch_size", "hny_builder_distances",
+    "hny_builder_finish", "hny_builder_destroy", "hny_builder_set_profiling", "hny_batch_size", "hny_builder_distances",
     "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
     "hny_encode_kv", "hny_last_error", "hny_version",
 ]
@@ -67,7 +67,10 @@ class GraphStruct(C.Structure):
                 ("n_evals_walk", C.c_uint64), ("n_evals_prune", C.c_uint64),
                 ("n_evals_apply", C.c_uint64), ("n_batches", C.c_uint64),
                 ("t_upload_s", C.c_double), ("t_build_s", C.c_double), ("t_export_s", C.c_double),
-                ("n_tie_pool_overflow", C.c_uint64)]
+                ("n_tie_pool_overflow", C.c_uint64),
+                ("t_walk_kernels_s", C.c_double), ("t_prune_kernels_s", C.c_double),
+                ("t_sort_kernels_s", C.c_double), ("t_apply_kernels_s", C.c_double),
+                ("n_walk_launches", C.c_uint64)]
 
 
 class Batch(C.Structure):
@@ -85,7 +88,7 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m hannoy_amd.build` "
+            f"{LIB_PATH} is missing: build it with `python -m hannoy_amd.buildlib` "
             "(hipcc --offload-arch=gfx950). hannoy_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
@@ -97,6 +100,8 @@ def load_library():
     for name in ("hny_builder_reset", "hny_builder_sync"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]
+    L.hny_builder_set_profiling.restype = C.c_int
+    L.hny_builder_set_profiling.argtypes = [vp, C.c_int]
     L.hny_builder_next_batch.restype = C.c_int
     L.hny_builder_next_batch.argtypes = [vp, C.POINTER(Batch)]
     L.hny_builder_search.restype = C.c_int
@@ -216,7 +221,8 @@ class Graph:
         self.max_level = g.max_level
         for f in ("n_links_added", "n_distance_evals", "n_evals_walk", "n_evals_prune",
                   "n_evals_apply", "n_batches", "t_upload_s", "t_build_s", "t_export_s",
-                  "n_tie_pool_overflow"):
+                  "n_tie_pool_overflow", "t_walk_kernels_s", "t_prune_kernels_s",
+                  "t_sort_kernels_s", "t_apply_kernels_s", "n_walk_launches"):
             setattr(self, f, getattr(g, f))
         self._gp, self._opts, self._items = gp, opts, items
 
@@ -282,6 +288,9 @@ class Builder:
 
     def reset(self):
         _check(load_library().hny_builder_reset(self._h))
+
+    def set_profiling(self, on=True):
+        _check(load_library().hny_builder_set_profiling(self._h, int(on)))
 
     def next_batch(self):
         b = Batch()

@@ -174,7 +174,38 @@ struct hny_builder {
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
   size_t max_ops = 0, sel_words = 0;
   double t_upload = 0, t_build0 = 0, t_build = 0;
+  // optional per-kernel-family timing (HIP events on `stream`)
+  struct Ev {
+    hipEvent_t a, b;
+    int kind;
+  };
+  std::vector<Ev> evs;
+  size_t ev_used = 0;
+  bool profiling = false;
+  ~hny_builder() {
+    for (auto &e : evs) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
+  }
 };
+enum { EV_WALK = 0, EV_PRUNE = 1, EV_SORT = 2, EV_APPLY = 3, EV_KINDS = 4 };
+static void prof_begin(hny_builder *b, int kind) {
+  if (!b->profiling) return;
+  if (b->ev_used == b->evs.size()) {
+    hny_builder::Ev e{};
+    e.kind = kind;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+    b->evs.push_back(e);
+  }
+  b->evs[b->ev_used].kind = kind;
+  (void)hipEventRecord(b->evs[b->ev_used].a, b->stream);
+}
+static void prof_end(hny_builder *b) {
+  if (!b->profiling || b->ev_used >= b->evs.size()) return;
+  (void)hipEventRecord(b->evs[b->ev_used].b, b->stream);
+  b->ev_used++;
+}
 
 namespace {
 
@@ -252,6 +283,7 @@ int reset_graph(hny_builder *b) {
   b->n_batches = 0;
   b->in_batch = false;
   b->finalized = false;
+  b->ev_used = 0;
   b->t_build0 = now_s();
   return HNY_OK;
 }
@@ -582,7 +614,9 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
+    prof_begin(b, EV_WALK);
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+    prof_end(b);
     PruneArgs p{};
     p.q_slots = w.q_slots;
     p.lo = lo;
@@ -596,7 +630,9 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     p.sel_stride = b->cur.sel_stride_u64;
     p.cap_sel = cs;
     p.batch_level = L;
+    prof_begin(b, EV_PRUNE);
     HIP_TRY(hnyk_prune(b->g, p, b->shape, grid, b->stream));
+    prof_end(b);
   }
   return HNY_OK;
 }
@@ -616,12 +652,14 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   e.batch_level = L;
   e.keys = b->d_keys_a.p;
   e.vals = b->d_vals_a.p;
+  prof_begin(b, EV_SORT);
   HIP_TRY(hnyk_emit(b->g, e, b->stream));
   size_t tmp = b->sort_tmp_bytes;
   HIP_TRY(hnyk_sort_pairs(b->d_sort_tmp.p, tmp, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, n_ops, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_nseg.p, 0, 4, b->stream));
   HIP_TRY(hnyk_segments(b->d_keys_b.p, n_ops, b->d_seg_start.p, b->d_nseg.p, b->stream));
+  prof_end(b);
   ApplyArgs a{};
   a.keys = b->d_keys_b.p;
   a.vals = b->d_vals_b.p;
@@ -629,11 +667,19 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   a.seg_start = b->d_seg_start.p;
   a.n_seg = b->d_nseg.p;
   const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
+  prof_begin(b, EV_APPLY);
   HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream));
+  prof_end(b);
   b->pos += b->cur.count;
   b->n_done += b->cur.count;
   b->n_batches++;
   b->in_batch = false;
+  return HNY_OK;
+}
+
+int hny_builder_set_profiling(hny_builder *b, int on) {
+  if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
+  b->profiling = on != 0;
   return HNY_OK;
 }
 
@@ -732,6 +778,22 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->t_upload_s = b->t_upload;
   g->t_build_s = b->t_build;
   g->t_export_s = now_s() - t0;
+  if (b->profiling) {
+    double acc[EV_KINDS] = {0};
+    uint64_t cnt[EV_KINDS] = {0};
+    for (size_t i = 0; i < b->ev_used; i++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, b->evs[i].a, b->evs[i].b) == hipSuccess) {
+        acc[b->evs[i].kind] += ms * 1e-3;
+        cnt[b->evs[i].kind]++;
+      }
+    }
+    g->t_walk_kernels_s = acc[EV_WALK];
+    g->t_prune_kernels_s = acc[EV_PRUNE];
+    g->t_sort_kernels_s = acc[EV_SORT];
+    g->t_apply_kernels_s = acc[EV_APPLY];
+    g->n_walk_launches = cnt[EV_WALK];
+  }
   *out = g;
   return HNY_OK;
 }

@@ -95,6 +95,10 @@ typedef struct {
   uint64_t n_batches;
   double t_upload_s, t_build_s, t_export_s; /* host wall clock of the three phases */
   uint64_t n_tie_pool_overflow; /* exactness counter, 0 in every supported case */
+  /* device time per kernel family, from HIP events on the build stream; filled only after
+   * hny_builder_set_profiling(b, 1) (else 0) */
+  double t_walk_kernels_s, t_prune_kernels_s, t_sort_kernels_s, t_apply_kernels_s;
+  uint64_t n_walk_launches;
 } hny_graph;
 
 typedef struct hny_builder hny_builder;
@@ -122,6 +126,8 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev);
 /* add_link for every selected pair, both directions (hnsw.rs:316-324, 523-560), in batch order */
 int hny_builder_apply(hny_builder *b, const void *sel_dev);
 int hny_builder_sync(hny_builder *b);
+/* record a HIP event pair around every kernel family launch (bench roofline accounting) */
+int hny_builder_set_profiling(hny_builder *b, int on);
 int hny_builder_finish(hny_builder *b, hny_graph **out);
 void hny_builder_destroy(hny_builder *b);
 /* the schedule: batch size when n_done items are already inserted */
