@@ -1,0 +1,186 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header declares,
+refuses to compute without a GPU, and its host-side codecs / record encoders agree byte for byte
+with the oracle and with hand-derived golden bytes.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hny():
+    import hannoy_amd
+    hannoy_amd.load_library()
+    return hannoy_amd
+
+
+def test_exports_every_declared_symbol(hny):
+    hdr = open(os.path.join(ROOT, "include", "hannoy_amd.h")).read()
+    declared = set(re.findall(r"\b(hny_[a-z_0-9]+)\s*\(", hdr)) - {"hny_kv_sink"}
+    lib = hny.load_library()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hannoy_amd.h but not exported"
+    from hannoy_amd import _capi
+    assert declared == set(_capi.EXPORTED)
+
+
+def test_no_cpu_fallback(hny):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    v = np.random.default_rng(0).uniform(-1, 1, (16, 8)).astype(np.float32)
+    items = hny.ItemSet.from_f32(hny.COSINE, v)
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items)
+    assert e.value.code == -6  # HNY_ERR_NO_DEVICE
+
+
+def test_argument_validation(hny):
+    v = np.random.default_rng(0).uniform(-1, 1, (4, 8)).astype(np.float32)
+    items = hny.ItemSet.from_f32(hny.EUCLIDEAN, v, ids=np.array([3, 2, 5, 9], np.uint32))
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items)
+    assert e.value.code == -1 and "ascending" in str(e.value)
+    items = hny.ItemSet.from_f32(hny.EUCLIDEAN, v)
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items, M=16, M0=8)
+    assert e.value.code == -1
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items, M=16, M0=128)
+    assert e.value.code == -5
+    bad = hny.ItemSet(hny.EUCLIDEAN, 16, items.ids, items.codes, items.headers)  # stride < 16*4
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(bad)
+    assert e.value.code == -4  # Error::InvalidVecDimension
+
+
+@pytest.mark.parametrize("metric", range(7))
+def test_codecs_match_oracle(hny, orc, metric):
+    rng = np.random.default_rng(metric)
+    for dim in (3, 20, 64, 100, 768):
+        v = rng.uniform(-1, 1, (50, dim)).astype(np.float32)
+        v[0, :] = 0.0
+        v[1, 0] = -0.0
+        v[2, 0] = np.inf
+        v[3, 0] = np.nan
+        codes, hdrs = hny.encode_vectors(metric, v)
+        ocodes = orc.encode_vectors(metric, v)
+        ohdrs = orc.make_headers(metric, dim, ocodes)
+        assert codes.shape == ocodes.shape and np.array_equal(codes, ocodes)
+        assert np.array_equal(hdrs, ohdrs)
+        assert hny.vector_bytes(metric, dim) == orc.vector_bytes(metric, dim)
+        assert hny.header_bytes(metric) == orc.header_bytes(metric)
+
+
+def test_quantiser_goldens(hny, kat):
+    for k in kat["kat6"]:
+        metric = hny.HAMMING if k["codec"] == "binary" else hny.BQ_COSINE
+        codes, _ = hny.encode_vectors(metric, np.array([k["input"]], np.float32))
+        assert [format(b, "08b") for b in codes[0]] == k["bytes_bin"], k["source"]
+
+
+def test_schedule_matches_oracle(hny, orc):
+    lib = hny.load_library()
+    for frac, bmax in ((0.02, 16384), (0.05, 64), (0.0, 1), (1.0, 7), (0.3, 0)):
+        for n_done in (0, 1, 2, 10, 49, 50, 51, 999, 12345, 10 ** 6, 10 ** 9):
+            assert lib.hny_batch_size(frac, bmax, n_done) == orc.batch_size(frac, bmax, n_done)
+
+
+def _graph_struct_from_oracle(hny, og):
+    from hannoy_amd import _capi
+    g = _capi.GraphStruct()
+    keep = [np.ascontiguousarray(og.rec_item, np.uint32), np.ascontiguousarray(og.rec_layer, np.uint8),
+            np.ascontiguousarray(og.offsets, np.uint64),
+            np.ascontiguousarray(og.nbrs if len(og.nbrs) else np.zeros(1), np.uint32),
+            np.ascontiguousarray(og.entry_points, np.uint32)]
+    g.n_records = len(og.rec_item)
+    g.rec_item = keep[0].ctypes.data_as(C.POINTER(C.c_uint32))
+    g.rec_layer = keep[1].ctypes.data_as(C.POINTER(C.c_uint8))
+    g.rec_offset = keep[2].ctypes.data_as(C.POINTER(C.c_uint64))
+    g.neighbours = keep[3].ctypes.data_as(C.POINTER(C.c_uint32))
+    g.entry_points = keep[4].ctypes.data_as(C.POINTER(C.c_uint32))
+    g.n_entry_points = len(og.entry_points)
+    g.max_level = og.max_level
+    return g, keep
+
+
+def _encode_kv(hny, g, opts, items, with_items):
+    from hannoy_amd import _capi
+    out = []
+
+    def sink(_c, k, kl, v, vl):
+        out.append((bytes(k[:kl]), bytes(v[:vl])))
+        return 0
+    it = items.struct()
+    rc = hny.load_library().hny_encode_kv(C.byref(g), C.byref(opts), C.byref(it), 0, with_items,
+                                          _capi.KV_SINK(sink), None)
+    assert rc == 0
+    return out
+
+
+def test_kv_records_kat1_bytes(hny, orc, kat):
+    """Byte-exact Key/Links/Metadata/Version/Item records for the KAT-1 index."""
+    k = kat["kat1"]
+    v = np.array(k["vectors"], np.float32)
+    ds = orc.Dataset.from_f32(orc.EUCLIDEAN, v, k["levels"])
+    og = orc.build(ds, M=3, M0=3, ef=100)
+    items = hny.ItemSet(hny.EUCLIDEAN, 2, ds.ids, ds.codes, ds.headers, ds.levels)
+    opts = hny.make_opts(hny.EUCLIDEAN, 2, M=3, M0=3)
+    g, _keep = _graph_struct_from_oracle(hny, og)
+    recs = _encode_kv(hny, g, opts, items, 1)
+    assert recs == orc.encode_kv(ds, og, 0, True)
+    keys = [r[0] for r in recs]
+    assert keys == sorted(keys)  # LMDB order: metadata, version, links by (item, layer), items
+    # metadata.rs:28-48, hand-assembled
+    roaring_items = bytes.fromhex("3a300000" "01000000" "0000" "0500" "10000000"
+                                  "0000" "0100" "0200" "0300" "0400" "0500")
+    meta = (b"euclidean\0" + (2).to_bytes(4, "big") + len(roaring_items).to_bytes(4, "big")
+            + roaring_items + b"".join(int(e).to_bytes(4, "little") for e in (0, 2, 3)) + b"\x01")
+    assert recs[0] == (bytes.fromhex("0000000000000000"), meta)
+    assert recs[1] == (bytes.fromhex("0000000000000100"), bytes.fromhex("000000000000000100000003"))
+    # Links(0, layer 0) = {1, 2}: node.rs:141-144 tag 1 + roaring
+    assert recs[2] == (bytes.fromhex("0000020000000000"),
+                       bytes.fromhex("01" "3a300000" "01000000" "0000" "0100" "10000000" "0100" "0200"))
+    # Item 5 = [5.0, 0.0], header bias 0.0: node.rs:136-140
+    assert recs[-1] == (bytes.fromhex("0000030000000500"),
+                        b"\x00" + np.float32(0).tobytes() + np.array([5, 0], np.float32).tobytes())
+    assert len(recs) == 2 + 9 + 6
+
+
+def test_roaring_serialisation_shapes(hny, orc):
+    """RoaringFormatSpec facts: empty bitmap = 8 bytes; array container up to 4096 values, bitmap
+    container (8 KiB) above; several 64Ki-containers; u32::MAX."""
+    assert orc.roaring_serialize([]) == bytes.fromhex("3a30000000000000")
+    ids = np.arange(0, 4096, dtype=np.uint32)
+    assert len(orc.roaring_serialize(ids)) == 8 + 8 + 2 * 4096
+    ids = np.arange(0, 4097, dtype=np.uint32)
+    assert len(orc.roaring_serialize(ids)) == 8 + 8 + 8192
+    ids = np.array([5, 70000, 4294967295], np.uint32)
+    b = orc.roaring_serialize(ids)
+    assert b == bytes.fromhex("3a300000" "03000000" "0000" "0000" "0100" "0000" "ffff" "0000"
+                              "20000000" "22000000" "24000000" "0500" "7011" "ffff")
+    # the product's encoder agrees on a large id set (metadata of a 100k-item index)
+    big = np.unique(np.random.default_rng(1).integers(0, 300000, 100000).astype(np.uint32))
+    ds_ids = big
+    v = np.zeros((len(big), 4), np.float32)
+    lv = np.zeros(len(big), np.uint8)
+    lv[0] = 1
+    items = hny.ItemSet.from_f32(hny.EUCLIDEAN, v, ids=ds_ids, levels=lv)
+
+    class G:
+        rec_item = np.zeros(0, np.uint32)
+        rec_layer = np.zeros(0, np.uint8)
+        offsets = np.zeros(1, np.uint64)
+        nbrs = np.zeros(0, np.uint32)
+        entry_points = big[:1]
+        max_level = 1
+    g, _keep = _graph_struct_from_oracle(hny, G)
+    recs = _encode_kv(hny, g, hny.make_opts(hny.EUCLIDEAN, 4), items, 0)
+    meta = recs[0][1]
+    rsz = int.from_bytes(meta[14:18], "big")
+    assert meta[18:18 + rsz] == orc.roaring_serialize(big)

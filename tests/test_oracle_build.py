@@ -1,0 +1,99 @@
+"""Host-side / oracle behaviour beyond the golden vectors: invariants the reference's tests assert
+(Reader::assert_validity reader.rs:905-948, all_items_are_reachable tests/reader.rs:82-98) and
+consistency between the oracle's build modes."""
+import numpy as np
+import pytest
+
+from conftest import draw_levels
+
+
+def _validity(g, ds):
+    """assert_validity (reader.rs:905-948): every link target exists; every item has >= 1 Links
+    key; entry points exist; + each item has one record per layer 0..=level."""
+    ids = set(ds.ids.tolist())
+    d = g.as_dict()
+    assert set(i for i, _ in d) == ids
+    for (i, l), nb in d.items():
+        assert set(nb) <= ids
+        assert nb == sorted(set(nb))
+    for e in g.entry_points:
+        assert int(e) in ids
+    for s, i in enumerate(ds.ids.tolist()):
+        for l in range(int(ds.levels[s]) + 1):
+            assert (i, l) in d
+    assert g.max_level == int(ds.levels.max())
+
+
+@pytest.mark.parametrize("metric,dim", [(0, 24), (1, 40), (3, 128)])
+def test_modes_agree_and_are_valid(orc, metric, dim):
+    rng = np.random.default_rng(dim)
+    n = 600
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds = orc.Dataset.from_f32(metric, vecs, draw_levels(n, 8, 3))
+    seq = orc.build(ds, M=8, M0=16, ef=32)
+    _validity(seq, ds)
+    b1 = orc.build(ds, M=8, M0=16, ef=32, batch_frac=0.5, batch_max=1)
+    assert seq.as_dict() == b1.as_dict()  # batch size 1 == sequential insertion
+    bt = orc.build(ds, M=8, M0=16, ef=32, batch_frac=0.1, batch_max=64)
+    _validity(bt, ds)
+    bt2 = orc.build(ds, M=8, M0=16, ef=32, batch_frac=0.1, batch_max=64, threads=4)
+    assert bt.as_dict() == bt2.as_dict()  # the batched schedule is deterministic under threads
+    th = orc.build(ds, M=8, M0=16, ef=32, threads=4)  # rayon-like: valid, not deterministic
+    _validity(th, ds)
+
+
+def test_all_items_are_reachable(orc):
+    """tests/reader.rs:82-98: M = M0 = 6, nns(n).ef_search(n) from the zero vector finds all."""
+    rng = np.random.default_rng(5)
+    n, dim = 400, 32
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds = orc.Dataset.from_f32(orc.COSINE, vecs, draw_levels(n, 6, 9))
+    for kw in ({}, {"batch_frac": 0.05, "batch_max": 32}):
+        g = orc.build(ds, M=6, M0=6, ef=100, **kw)
+        q = np.zeros((1, dim), np.float32)
+        qc = orc.encode_vectors(orc.COSINE, q)
+        qh = orc.make_headers(orc.COSINE, dim, qc)
+        ids, dists, counts = orc.search(ds, g, qc, qh, k=n, ef_search=n)
+        assert counts[0] == n and sorted(ids[0].tolist()) == list(range(n))
+
+
+def test_recall_sequential_vs_batched(orc):
+    """The batch-synchronous schedule (GPU semantics) keeps recall@10 within 0.5 % of the
+    sequential reference semantics (north-star tolerance), small case."""
+    rng = np.random.default_rng(11)
+    n, dim, nq = 4000, 48, 200
+    centres = rng.uniform(-1, 1, (32, dim))
+    vecs = (centres[rng.integers(0, 32, n)] + 0.2 * rng.normal(size=(n, dim))).astype(np.float32)
+    qs = (centres[rng.integers(0, 32, nq)] + 0.2 * rng.normal(size=(nq, dim))).astype(np.float32)
+    ds = orc.Dataset.from_f32(orc.EUCLIDEAN, vecs, draw_levels(n, 16, 2))
+    qc = orc.encode_vectors(orc.EUCLIDEAN, qs)
+    qh = orc.make_headers(orc.EUCLIDEAN, dim, qc)
+    d2 = ((qs[:, None, :].astype(np.float64) - vecs[None, :, :]) ** 2).sum(-1)
+    truth = np.argsort(d2, axis=1)[:, :10]
+
+    def recall(g):
+        ids, _, cnt = orc.search(ds, g, qc, qh, k=10, ef_search=100)
+        return sum(len(set(ids[i, :cnt[i]].tolist()) & set(truth[i].tolist())) for i in range(nq)) / (10 * nq)
+    r_seq = recall(orc.build(ds, M=16, M0=32, ef=100))
+    r_bat = recall(orc.build(ds, M=16, M0=32, ef=100, batch_frac=0.02, batch_max=16384))
+    assert r_seq > 0.95
+    assert abs(r_seq - r_bat) <= 0.005
+
+
+def test_wave_and_x86_orders_build_equivalent_graphs(orc):
+    """Different f32 summation orders (reference x86 vs GPU wave order) change distances by a few
+    ulp; on integer-valued data (exact in f32) the graphs must be identical."""
+    rng = np.random.default_rng(3)
+    n, dim = 500, 64
+    vecs = rng.integers(-8, 9, (n, dim)).astype(np.float32)
+    ds = orc.Dataset.from_f32(orc.EUCLIDEAN, vecs, draw_levels(n, 8, 4))
+    a = orc.build(ds, M=8, M0=16, ef=40, order=orc.ORDER_X86)
+    b = orc.build(ds, M=8, M0=16, ef=40, order=orc.ORDER_WAVE)
+    assert a.as_dict() == b.as_dict()
+
+
+def test_empty_and_single(orc):
+    ds = orc.Dataset(orc.COSINE, 4, np.zeros(0, np.uint32), np.zeros((0, 16), np.uint8),
+                     np.zeros((0, 4), np.uint8), np.zeros(0, np.uint8))
+    g = orc.build(ds)
+    assert len(g.rec_item) == 0 and len(g.entry_points) == 0
