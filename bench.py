@@ -177,7 +177,7 @@ def main():
         "config": {"workload": f"C2: {a.n} x {a.dim} {a.metric}, M={a.M} M0={M0} efC={a.ef}, "
                                f"{a.data} synthetic vectors resident in HBM, 1 step = 1 full build",
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
-                   "batch_frac": builder.opts.batch_frac or 0.02,
+                   "batch_frac": builder.opts.batch_frac or 0.25,
                    "batch_max": builder.opts.batch_max or 16384,
                    "parallelism": f"item-sharded search x{world}, replicated graph"},
         "roofline": roof,

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhannoy_amd.so")
+LIB_PATH = os.environ.get("HNY_LIB") or os.path.join(HERE, "libhannoy_amd.so")
 
 COSINE, EUCLIDEAN, MANHATTAN, HAMMING, BQ_COSINE, BQ_EUCLIDEAN, BQ_MANHATTAN = range(7)
 METRIC_NAMES = ["cosine", "euclidean", "manhattan", "hamming", "binary quantized cosine",

@@ -13,7 +13,7 @@ HEADERS = [os.path.join(CSRC, "hny_internal.h"),
 # correctly rounded f32 divide/sqrt for the cosine / hamming finalisers.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("HNY_CFLAGS", "").split()
 
 
 def hipcc():

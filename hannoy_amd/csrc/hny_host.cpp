@@ -167,11 +167,13 @@ struct hny_builder {
   DevBuf<float> d_norms, d_l0_dist, d_up_dist;
   DevBuf<int> d_upper_idx;
   DevBuf<u32> d_l0_ids, d_l0_cnt, d_up_ids, d_up_cnt, d_order, d_eps, d_bits, d_vlog, d_cand_n,
-      d_seg_start, d_nseg;
+      d_seg_start, d_nseg, d_deferred;
   DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
+  int stage_rows = 0;      // selected rows staged in LDS by the workgroup prune kernels
+  bool wave_prune_only = false;
   size_t max_ops = 0, sel_words = 0;
   double t_upload = 0, t_build0 = 0, t_build = 0;
   // optional per-kernel-family timing (HIP events on `stream`)
@@ -401,7 +403,7 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   b->o = o;
   b->n = (uint32_t)items->n;
   const uint32_t n = b->n;
-  b->frac = o.batch_frac > 0.0 ? o.batch_frac : 0.02;
+  b->frac = o.batch_frac > 0.0 ? o.batch_frac : 0.25;
   b->bmax = o.batch_max ? o.batch_max : 16384u;
   uint32_t n16;
   int rc = pick_shape(o.metric, o.dim, b->shape, n16);
@@ -473,6 +475,14 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   b->walk_slots = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_WALK_SLOTS", 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
+  {
+    // LDS staging budget of the workgroup prune: <= 48 KiB of rows, whole load groups
+    int rpg = 64 / b->shape.lpr;
+    int sl = (int)((u32)std::max(0, env_int("HNY_STAGE_BYTES", 24576)) / (n16 * 16u));
+    if (sl > HNY_MAX_CAP) sl = HNY_MAX_CAP;
+    b->stage_rows = sl / rpg * rpg;
+    b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0;
+  }
 
   // ---- device memory ----
   GraphDev &g = b->g;
@@ -516,7 +526,8 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   HIP_TRY(b->d_vals_a.alloc(b->max_ops));
   HIP_TRY(b->d_vals_b.alloc(b->max_ops));
   HIP_TRY(b->d_seg_start.alloc(b->max_ops));
-  HIP_TRY(b->d_nseg.alloc(1));
+  HIP_TRY(b->d_nseg.alloc(2));
+  HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, (u32)b->max_ops, st));
   HIP_TRY(b->d_sort_tmp.alloc(b->sort_tmp_bytes + 16));
@@ -631,7 +642,11 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     p.cap_sel = cs;
     p.batch_level = L;
     prof_begin(b, EV_PRUNE);
-    HIP_TRY(hnyk_prune(b->g, p, b->shape, grid, b->stream));
+    if (b->wave_prune_only)
+      HIP_TRY(hnyk_prune(b->g, p, b->shape, grid, b->stream));
+    else
+      HIP_TRY(hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, (int)std::min<uint32_t>(hi - lo, 2048),
+                            b->stream));
     prof_end(b);
   }
   return HNY_OK;
@@ -657,7 +672,7 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   size_t tmp = b->sort_tmp_bytes;
   HIP_TRY(hnyk_sort_pairs(b->d_sort_tmp.p, tmp, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, n_ops, b->stream));
-  HIP_TRY(hipMemsetAsync(b->d_nseg.p, 0, 4, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_nseg.p, 0, 8, b->stream));
   HIP_TRY(hnyk_segments(b->d_keys_b.p, n_ops, b->d_seg_start.p, b->d_nseg.p, b->stream));
   prof_end(b);
   ApplyArgs a{};
@@ -666,9 +681,14 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   a.n_ops = n_ops;
   a.seg_start = b->d_seg_start.p;
   a.n_seg = b->d_nseg.p;
+  a.deferred = b->wave_prune_only ? nullptr : b->d_deferred.p;
+  a.n_deferred = b->d_nseg.p + 1;
   const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
   prof_begin(b, EV_APPLY);
   HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream));
+  if (!b->wave_prune_only)
+    HIP_TRY(hnyk_apply_wg(b->g, a, b->shape, b->stage_rows,
+                          (int)std::min<u32>(std::max<u32>(n_ops / 8, 1), 2048), b->stream));
   prof_end(b);
   b->pos += b->cur.count;
   b->n_done += b->cur.count;

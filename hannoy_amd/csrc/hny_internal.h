@@ -109,6 +109,8 @@ struct ApplyArgs {
   u32 n_ops;
   const u32 *seg_start;
   const u32 *n_seg;
+  u32 *deferred;   // segments whose list may overflow (handled by k_apply_wg); null = do all here
+  u32 *n_deferred;
 };
 
 struct LaunchShape {
@@ -122,6 +124,10 @@ hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int 
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st);
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st);
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid,
+                         hipStream_t st);
+hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
+                         hipStream_t st);
 hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
                            u64 *vals_out, u32 n, hipStream_t st);
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,

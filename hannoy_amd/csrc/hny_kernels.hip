@@ -23,6 +23,13 @@
 namespace {
 
 __device__ __forceinline__ u32 fbits(float f) { return __float_as_uint(f); }
+// wave-uniform values that were read from LDS or produced by a cross-lane reduction sit in VGPRs;
+// readfirstlane moves them to SGPRs (lower VGPR pressure, scalar branches)
+__device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ u64 uni(u64 x) {
+  return ((u64)uni((u32)(x >> 32)) << 32) | (u64)uni((u32)(x & 0xFFFFFFFFull));
+}
 
 // ---------------------------------------------------------------------------------------------
 // distance inner loops.  Lane t of an LPR-lane group owns 16-byte unit #(c*LPR + t), c < NCH.
@@ -36,6 +43,26 @@ __device__ __forceinline__ void load_row(const unsigned char *p, int t, u32 n16,
     u32 f = (u32)(c * LPR + t);
     r[c] = f < n16 ? *reinterpret_cast<const float4 *>(p + (size_t)f * 16)
                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// same, from an LDS image of the row.  The pointer is cast to address space 3 explicitly: a generic
+// pointer here makes hipcc emit flat_load, whose waits (vmcnt(0) + lgkmcnt(0)) serialise against
+// every HBM load in flight.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x4_t lds_cf4;
+template <int LPR, int NCH>
+__device__ __forceinline__ void load_row_lds(const unsigned char *p, int t, u32 n16, float4 (&r)[NCH]) {
+  const unsigned lp = (unsigned)(size_t)p; // low 32 bits of a generic LDS address = LDS offset
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    u32 f = (u32)(c * LPR + t);
+    if (f < n16) {
+      f32x4_t v = *reinterpret_cast<lds_cf4 *>((size_t)(lp + f * 16u));
+      r[c] = make_float4(v.x, v.y, v.z, v.w);
+    } else {
+      r[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -97,6 +124,57 @@ __device__ __forceinline__ u32 butterfly_u32(u32 v) {
 #pragma unroll
   for (int off = LPR / 2; off >= 1; off >>= 1) v = v + (u32)__shfl_xor((int)v, off, 64);
   return v;
+}
+
+// Folded butterflies.  The xor butterfly computes, at every step, v[t] + v[t ^ off] on all lanes, so
+// lanes t and t ^ off hold the same value.  When R rows are reduced together the two halves can work
+// on DIFFERENT rows instead of duplicating each other: the pair sums are the very same f32
+// additions (bit-identical result), but 4 rows cost 2+1+(log2(LPR)-2) shuffles instead of
+// 4*log2(LPR).  Row j of a fold4 ends up in the lanes with bit(LPR/2) == (j & 1) and
+// bit(LPR/4) == (j >> 1); fold2: bit(LPR/2) == j.
+template <typename T>
+__device__ __forceinline__ T fold_step(T a, T b, int off) {
+  const bool hi = (threadIdx.x & off) != 0;
+  T keep = hi ? b : a, send = hi ? a : b;
+  T recv;
+  if constexpr (sizeof(T) == 4 && __is_same(T, float))
+    recv = __shfl_xor(send, off, 64);
+  else
+    recv = (T)__shfl_xor((int)send, off, 64);
+  return keep + recv;
+}
+template <int LPR, typename T>
+__device__ __forceinline__ T fold4(T p0, T p1, T p2, T p3) {
+  T x01 = fold_step<T>(p0, p1, LPR / 2), x23 = fold_step<T>(p2, p3, LPR / 2);
+  T y = fold_step<T>(x01, x23, LPR / 4);
+#pragma unroll
+  for (int off = LPR / 8; off >= 1; off >>= 1) {
+    if constexpr (__is_same(T, float))
+      y = y + __shfl_xor(y, off, 64);
+    else
+      y = y + (T)__shfl_xor((int)y, off, 64);
+  }
+  return y;
+}
+template <int LPR, typename T>
+__device__ __forceinline__ T fold2(T p0, T p1) {
+  T y = fold_step<T>(p0, p1, LPR / 2);
+#pragma unroll
+  for (int off = LPR / 4; off >= 1; off >>= 1) {
+    if constexpr (__is_same(T, float))
+      y = y + __shfl_xor(y, off, 64);
+    else
+      y = y + (T)__shfl_xor((int)y, off, 64);
+  }
+  return y;
+}
+template <int LPR>
+__device__ __forceinline__ int fold4_row() { // which of the 4 rows this lane's fold4 result belongs to
+  return (int)((threadIdx.x / (LPR / 2)) & 1) | (int)(((threadIdx.x / (LPR / 4)) & 1) << 1);
+}
+template <int LPR>
+__device__ __forceinline__ int fold2_row() {
+  return (int)((threadIdx.x / (LPR / 2)) & 1);
 }
 
 __device__ __forceinline__ float finalize_f32(const GraphDev &g, float acc, float qn, float rn) {
@@ -167,19 +245,47 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
         for (int c = 0; c < NCH; c++) r[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    // reduce the U load groups 4 (or 2) at a time with folded butterflies
+    constexpr int F = (U % 4 == 0) ? 4 : 2;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (k0 + u * RPG < n) {
+    for (int u0 = 0; u0 < U; u0 += F) {
+      if (k0 + u0 * RPG < n) { // wave-uniform
+        int j;
         float d;
         if (g.mclass == MC_BIN) {
-          u32 pc = butterfly_u32<LPR>(partial_bin<NCH>(q, r[u]));
-          d = finalize_bin(g, pc, qn, rn[u]);
+          u32 pc;
+          if constexpr (F == 4) {
+            pc = fold4<LPR, u32>(partial_bin<NCH>(q, r[u0]), partial_bin<NCH>(q, r[u0 + 1]),
+                                 partial_bin<NCH>(q, r[u0 + 2]), partial_bin<NCH>(q, r[u0 + 3]));
+            j = fold4_row<LPR>();
+          } else {
+            pc = fold2<LPR, u32>(partial_bin<NCH>(q, r[u0]), partial_bin<NCH>(q, r[u0 + 1]));
+            j = fold2_row<LPR>();
+          }
+          float rnj = rn[u0];
+#pragma unroll
+          for (int jj = 1; jj < F; jj++) rnj = (j == jj) ? rn[u0 + jj] : rnj;
+          d = finalize_bin(g, pc, qn, rnj);
         } else {
-          float pa = butterfly_f32<LPR>(partial_f32<NCH>(g.mclass, q, r[u]));
-          d = finalize_f32(g, pa, qn, rn[u]);
+          float pa;
+          if constexpr (F == 4) {
+            pa = fold4<LPR, float>(partial_f32<NCH>(g.mclass, q, r[u0]),
+                                   partial_f32<NCH>(g.mclass, q, r[u0 + 1]),
+                                   partial_f32<NCH>(g.mclass, q, r[u0 + 2]),
+                                   partial_f32<NCH>(g.mclass, q, r[u0 + 3]));
+            j = fold4_row<LPR>();
+          } else {
+            pa = fold2<LPR, float>(partial_f32<NCH>(g.mclass, q, r[u0]),
+                                   partial_f32<NCH>(g.mclass, q, r[u0 + 1]));
+            j = fold2_row<LPR>();
+          }
+          float rnj = rn[u0];
+#pragma unroll
+          for (int jj = 1; jj < F; jj++) rnj = (j == jj) ? rn[u0 + jj] : rnj;
+          d = finalize_f32(g, pa, qn, rnj);
         }
-        int ri = k0 + u * RPG + sub;
-        if (t == 0 && ri < n) out[ri] = d;
+        int ri = k0 + (u0 + j) * RPG + sub;
+        if ((t & (LPR / F - 1)) == 0 && ri < n) out[ri] = d;
       }
     }
   }
@@ -280,7 +386,7 @@ __device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
     pos += __popcll(__ballot(lt));
   }
   const bool evict = (len == ef);
-  const u64 oldmax = len ? s.res[len - 1] : 0ull;
+  const u64 oldmax = len ? uni(s.res[len - 1]) : 0ull;
   if (evict && pos == len) { // the new entry is the max: pushed and popped at once
     beam_evicted(s, key, (u32)(oldmax >> 32));
     return;
@@ -306,7 +412,7 @@ __device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
     s.res_len = len + 1;
     return;
   }
-  const u32 nd = (u32)(s.res[len - 1] >> 32);
+  const u32 nd = uni((u32)(s.res[len - 1] >> 32));
   if (s.pool_len - s.n_weird > 0 && s.tie_bits != nd) pool_drop_ties(s);
   beam_evicted(s, oldmax, nd);
 }
@@ -374,7 +480,7 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
     evals += (u64)n_eps;
     WSYNC();
     for (int r = 0; r < n_eps; r++) {
-      u64 key = ((u64)fbits(nb_d[r]) << 32) | ((u64)nb_ids[r] << 1);
+      u64 key = ((u64)uni(fbits(nb_d[r])) << 32) | ((u64)uni(nb_ids[r]) << 1);
       beam_insert(s, key, 0x7FFFFFFF);
     }
   }
@@ -395,21 +501,21 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
         break;
       }
     }
-    const u32 dmax = (u32)(s.res[s.res_len - 1] >> 32);
+    const u32 dmax = uni((u32)(s.res[s.res_len - 1] >> 32));
     // pop-order key: distance bits ascending, then id DESCENDING
     u64 ta = ~0ull;
     int last = first_un;
     if (first_un >= 0) {
-      const u32 d0 = (u32)(s.res[first_un] >> 32);
+      const u32 d0 = uni((u32)(s.res[first_un] >> 32));
       for (int base = first_un & ~63; base < s.res_len; base += 64) {
         int e = base + ln;
         bool ok = e >= first_un && e < s.res_len && (u32)(s.res[e] >> 32) == d0 && !(s.res[e] & 1ull);
         u64 mk = __ballot(ok);
         if (mk) last = base + 63 - __clzll((long long)mk);
         int ce = base + 63 < s.res_len - 1 ? base + 63 : s.res_len - 1;
-        if ((u32)(s.res[ce] >> 32) != d0) break;
+        if (uni((u32)(s.res[ce] >> 32)) != d0) break;
       }
-      ta = ((u64)d0 << 32) | (u64)(~(u32)(s.res[last] & 0xFFFFFFFEull));
+      ta = ((u64)d0 << 32) | (u64)(~uni((u32)(s.res[last] & 0xFFFFFFFEull)));
     }
     u64 tp = ~0ull;
     int pi = -1;
@@ -431,6 +537,8 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
           pi = oi;
         }
       }
+      tp = uni(tp);
+      pi = uni(pi);
     }
     const bool have_a = first_un >= 0, have_p = pi >= 0;
     if (!have_a && !have_p) break; // candidates exhausted (or only dropped entries: they break)
@@ -442,14 +550,14 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
     u32 cslot;
     if (use_pool) {
       cslot = (~(u32)(tp & 0xFFFFFFFFull)) >> 1;
-      u64 lastk = s.pool[s.pool_len - 1];
+      u64 lastk = uni(s.pool[s.pool_len - 1]);
       WSYNC();
       if (ln == 0) s.pool[pi] = lastk;
       s.pool_len--;
       if (weird_bits(fb)) s.n_weird--;
       WSYNC();
     } else {
-      cslot = (u32)(s.res[last] >> 1) & 0x7FFFFFFFu;
+      cslot = uni((u32)(s.res[last] >> 1) & 0x7FFFFFFFu);
       WSYNC();
       if (ln == 0) s.res[last] |= 1ull;
       WSYNC();
@@ -501,15 +609,18 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
     while (amask) {
       int r = __ffsll((long long)amask) - 1;
       amask &= amask - 1ull;
-      u32 db = fbits(__shfl(myd, r, 64));
-      u32 idr = (u32)__shfl((int)myid, r, 64);
+      u32 db = (u32)__builtin_amdgcn_readlane((int)fbits(myd), r);
+      u32 idr = (u32)__builtin_amdgcn_readlane((int)myid, r);
       beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
     }
   }
 }
 
+#ifndef HNY_WALK_WPE
+#define HNY_WALK_WPE 4
+#endif
 template <int LPR, int NCH>
-__global__ __launch_bounds__(64) void k_walk(GraphDev g, WalkArgs a) {
+__global__ __launch_bounds__(64, HNY_WALK_WPE) void k_walk(GraphDev g, WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
@@ -668,6 +779,223 @@ __global__ __launch_bounds__(64) void k_prune(GraphDev g, PruneArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// robust_prune with a 256-thread workgroup and the selected rows staged in LDS.  k_prune (one wave,
+// selected rows re-read from HBM for every candidate) fetched 1.6 TB at C2 (profiles/r01 PMC); here
+// every candidate row is read from HBM once (prefetched one candidate ahead) and compared against
+// the selected rows held in LDS; the 4 waves split the selected rows.  Same distances, same result.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__device__ __forceinline__ float pair_distance(const GraphDev &g, const float4 (&a)[NCH], float an,
+                                               const float4 (&b)[NCH], float bn) {
+  if (g.mclass == MC_BIN) return finalize_bin(g, butterfly_u32<LPR>(partial_bin<NCH>(a, b)), an, bn);
+  return finalize_f32(g, butterfly_f32<LPR>(partial_f32<NCH>(g.mclass, a, b)), an, bn);
+}
+
+struct WgPruneLds {
+  u64 *S;          // [HNY_MAX_CAP] selected keys
+  u32 *s_ids;      // [HNY_MAX_CAP]
+  float *s_norm;   // [HNY_MAX_CAP]
+  int *surv;       // [4] chunk member survived the test against S
+  u32 *vmask;      // [4] bit j: chunk member violates against chunk member j
+  float *cnorm;    // [4]
+  unsigned char *cbuf;  // [4][row_stride] the chunk's candidate rows
+  unsigned char *stage; // [SL][row_stride] selected rows
+  int SL;          // staged rows (multiple of 64/LPR)
+};
+
+// robust_prune for a 4-wave workgroup.  `exists i in S: bits(d(c,i)*alpha) < bits(dq)` does not
+// depend on the order in which S is scanned, so 4 consecutive candidates are tested concurrently,
+// one per wave, against the selected set as it stood before the chunk (rows from LDS, early exit);
+// the survivors are then tested against each other (rows exchanged through LDS) and the chunk is
+// resolved in candidate order — exactly the sequential outcome, with 3 barriers per 4 candidates.
+// Each wave streams its next candidate row from HBM one chunk ahead.
+template <int LPR, int NCH>
+__device__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, const WgPruneLds &L,
+                        u64 &evals) {
+  constexpr int RPG = 64 / LPR;
+  constexpr int NW = 4;
+  const int tid = threadIdx.x, w = tid >> 6, ln = tid & 63, t = ln % LPR, sub = ln / LPR;
+  const int j4 = fold4_row<LPR>();
+  int s_len = 0;
+  float4 nxt[NCH];
+  float nxt_n = 0.f;
+  if (w < n) {
+    const u32 c0 = (u32)(list[w] & 0xFFFFFFFFull);
+    load_row<LPR, NCH>(g.rows + (size_t)c0 * g.row_stride, t, g.n16, nxt);
+    if (g.norms) nxt_n = g.norms[c0];
+  }
+  __syncthreads();
+  for (int base = 0; base < n && s_len < cap; base += NW) {
+    const int ci = base + w;
+    const bool have = ci < n;
+    float4 c[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; k++) c[k] = nxt[k];
+    const float cn = nxt_n;
+    const u64 ck = have ? list[ci] : 0ull;
+    const u32 cid = (u32)(ck & 0xFFFFFFFFull), cdb = (u32)(ck >> 32);
+    // A: publish this wave's candidate row for the intra-chunk tests, start the next one
+    unsigned char *cb = L.cbuf + (size_t)w * g.row_stride;
+    if (have && sub == 0) {
+#pragma unroll
+      for (int k = 0; k < NCH; k++) {
+        u32 f = (u32)(k * LPR + t);
+        if (f < g.n16) *reinterpret_cast<float4 *>(cb + (size_t)f * 16) = c[k];
+      }
+    }
+    if (ci + NW < n) {
+      const u32 nx = (u32)(list[ci + NW] & 0xFFFFFFFFull);
+      load_row<LPR, NCH>(g.rows + (size_t)nx * g.row_stride, t, g.n16, nxt);
+      if (g.norms) nxt_n = g.norms[nx];
+    }
+    // B: this wave's candidate against S (wave-local)
+    bool viol = false;
+    const int ngroups = (s_len + RPG - 1) / RPG;
+    if (have) {
+      for (int g0 = 0; g0 < ngroups && !viol; g0 += 4) {
+        float4 r[4][NCH];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int gi = g0 + j;
+          if (gi < ngroups) { // wave-uniform
+            int ri = gi * RPG + sub;
+            if (ri > s_len - 1) ri = s_len - 1;
+            if (gi * RPG < L.SL)
+              load_row_lds<LPR, NCH>(L.stage + (size_t)ri * g.row_stride, t, g.n16, r[j]);
+            else
+              load_row<LPR, NCH>(g.rows + (size_t)L.s_ids[ri] * g.row_stride, t, g.n16, r[j]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) r[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        const int myri = (g0 + j4) * RPG + sub;
+        const bool on = myri < s_len;
+        const float rn = L.s_norm[on ? myri : 0];
+        float d;
+        if (g.mclass == MC_BIN)
+          d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
+                                              partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
+                           cn, rn);
+        else
+          d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
+                                                partial_f32<NCH>(g.mclass, c, r[1]),
+                                                partial_f32<NCH>(g.mclass, c, r[2]),
+                                                partial_f32<NCH>(g.mclass, c, r[3])),
+                           cn, rn);
+        const float da = d * g.alpha; // hnsw.rs:585
+        viol = __ballot(on && fbits(da) < cdb) != 0ull;
+        if (ln == 0) {
+          int done = ngroups - g0;
+          evals += (u64)(done < 4 ? done : 4) * RPG;
+        }
+      }
+    }
+    const bool surv = have && !viol;
+    if (ln == 0) {
+      L.surv[w] = surv ? 1 : 0;
+      L.cnorm[w] = cn;
+    }
+    __syncthreads();
+    // C: survivors against the earlier members of the chunk (one folded pass over cbuf[0..3])
+    u32 vm = 0;
+    if (surv && w > 0) {
+      float4 r[4][NCH];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        load_row_lds<LPR, NCH>(L.cbuf + (size_t)j * g.row_stride, t, g.n16, r[j]);
+      const float rn = L.cnorm[j4];
+      float d;
+      if (g.mclass == MC_BIN)
+        d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
+                                            partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
+                         cn, rn);
+      else
+        d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
+                                              partial_f32<NCH>(g.mclass, c, r[1]),
+                                              partial_f32<NCH>(g.mclass, c, r[2]),
+                                              partial_f32<NCH>(g.mclass, c, r[3])),
+                         cn, rn);
+      const float da = d * g.alpha;
+      const bool hit = sub == 0 && j4 < w && L.surv[j4] != 0 && fbits(da) < cdb;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << j;
+      if (ln == 0) evals += (u64)w;
+    }
+    if (ln == 0) L.vmask[w] = vm;
+    __syncthreads();
+    // D: resolve the chunk in candidate order (every thread computes the same thing)
+    u32 selmask = 0;
+    int cnt = s_len;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      if (cnt < cap && L.surv[j] != 0 && (L.vmask[j] & selmask) == 0u) { // :577-579, :583-592
+        selmask |= 1u << j;
+        cnt++;
+      }
+    }
+    if ((selmask >> w) & 1u) {
+      const int pos = s_len + __popc(selmask & ((1u << w) - 1u));
+      if (ln == 0) {
+        L.S[pos] = ck;
+        L.s_ids[pos] = cid;
+        L.s_norm[pos] = cn;
+      }
+      if (sub == 0 && pos < L.SL) {
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+          u32 f = (u32)(k * LPR + t);
+          if (f < g.n16)
+            *reinterpret_cast<float4 *>(L.stage + (size_t)pos * g.row_stride + (size_t)f * 16) = c[k];
+        }
+      }
+    }
+    s_len = cnt;
+    __syncthreads();
+  }
+  return s_len;
+}
+
+__host__ __device__ inline size_t wg_prune_lds_bytes(u32 rcap, u32 row_stride, int SL) {
+  return (size_t)rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4) + 64 + (size_t)(SL + 4) * row_stride;
+}
+
+__device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL, u32 row_stride) {
+  WgPruneLds L;
+  L.S = reinterpret_cast<u64 *>(base);
+  L.s_ids = reinterpret_cast<u32 *>(L.S + HNY_MAX_CAP);
+  L.s_norm = reinterpret_cast<float *>(L.s_ids + HNY_MAX_CAP);
+  L.surv = reinterpret_cast<int *>(L.s_norm + HNY_MAX_CAP);
+  L.vmask = reinterpret_cast<u32 *>(L.surv + 4);
+  L.cnorm = reinterpret_cast<float *>(L.vmask + 4);
+  L.cbuf = reinterpret_cast<unsigned char *>(L.cnorm + 8);
+  L.stage = L.cbuf + 4 * (size_t)row_stride;
+  L.SL = SL;
+  return L;
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_prune_wg(GraphDev g, PruneArgs a, int SL) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *list = reinterpret_cast<u64 *>(smem);
+  WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride);
+  const int tid = threadIdx.x;
+  u64 evals = 0;
+  for (u32 m = a.lo + blockIdx.x; m < a.hi; m += gridDim.x) {
+    const int n = (int)a.cand_n[m];
+    for (int e = tid; e < n; e += blockDim.x) list[e] = a.cand[(size_t)m * a.rcap + e];
+    __syncthreads();
+    const int s_len = wg_prune<LPR, NCH>(g, list, n, (int)a.cap, L, evals);
+    u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
+    if (tid == 0) out[0] = (u64)s_len;
+    if (tid < s_len) out[1 + tid] = L.S[tid];
+    __syncthreads();
+  }
+  if ((tid & 63) == 0 && evals) atomicAdd(&g.stats[ST_EVALS_PRUNE], evals);
+}
+
+// ---------------------------------------------------------------------------------------------
 // link ops.  For batch member m (in batch order), layer l from its level down to 0, k-th selected
 // (d, n): LINK(q,(d,n),l) then LINK(n,(d,q),l) (hnsw.rs:316-324).  key = layer:3 | target:31 |
 // seq:30 — a full 64-bit sort groups ops by target and keeps the reference's sequential order
@@ -739,6 +1067,22 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
     u32 cw = *cntp;
     int cnt = (int)(cw & 0xFFFFu);
     bool frozen = (cw >> 31) != 0u;
+    // a frozen list never changes again (see below): nothing to do for any number of ops
+    if (frozen) continue;
+    if (a.deferred) {
+      // count the segment's ops; if the list can overflow, leave the whole segment to k_apply_wg
+      u32 nops = 0;
+      for (u32 i = i0; i < a.n_ops; i++) {
+        const u64 key = a.keys[i];
+        if (key == HNY_OP_INVALID || (key >> 30) != k0) break;
+        nops++;
+        if (cnt + (int)nops > (int)cap) break;
+      }
+      if (cnt + (int)nops > (int)cap) {
+        if (ln == 0) a.deferred[atomicAdd(a.n_deferred, 1u)] = sg;
+        continue;
+      }
+    }
     if (ln < cnt) lk[ln] = ((u64)fbits(dist[ln]) << 32) | ids[ln];
     WSYNC();
     for (u32 i = i0; i < a.n_ops; i++) {
@@ -777,6 +1121,79 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
     WSYNC();
   }
   if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
+}
+
+// add_link for the segments k_apply deferred (their list overflows): 256 threads per segment, the
+// self-prune runs on the LDS-staged wg_prune.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int SL) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *lk = reinterpret_cast<u64 *>(smem);          // [HNY_MAX_CAP] the node's list
+  u64 *sorted = lk + HNY_MAX_CAP;                   // [HNY_MAX_CAP]
+  WgPruneLds L = wg_prune_carve(smem + (size_t)2 * HNY_MAX_CAP * 8, SL, g.row_stride);
+  const int tid = threadIdx.x;
+  const u32 n_def = *a.n_deferred;
+  u64 evals = 0;
+  for (u32 di = blockIdx.x; di < n_def; di += gridDim.x) {
+    const u32 sg = a.deferred[di];
+    const u32 i0 = a.seg_start[sg];
+    const u64 k0 = a.keys[i0] >> 30;
+    const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
+    u32 cap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)target * g.M0;
+      dist = g.l0_dist + (size_t)target * g.M0;
+      cntp = g.l0_cnt + target;
+    } else {
+      size_t u = (size_t)g.upper_idx[target] * g.max_level + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    const u32 cw = *cntp;
+    int cnt = (int)(cw & 0xFFFFu);
+    bool frozen = (cw >> 31) != 0u;
+    if (tid < cnt) lk[tid] = ((u64)fbits(dist[tid]) << 32) | ids[tid];
+    __syncthreads();
+    for (u32 i = i0; i < a.n_ops && !frozen; i++) {
+      const u64 key = a.keys[i];
+      if (key == HNY_OP_INVALID || (key >> 30) != k0) break;
+      const u64 val = a.vals[i];
+      if ((u32)(val & 0xFFFFFFFFull) == target) continue; // hnsw.rs:530
+      if (cnt < (int)cap) {                               // :542-545
+        if (tid == 0) lk[cnt] = val;
+        cnt++;
+        __syncthreads();
+      } else { // :547-552
+        if (tid < cnt) {
+          const u64 mine = lk[tid];
+          int rk = 0;
+          for (int j = 0; j < cnt; j++) {
+            u64 o = lk[j];
+            rk += (o < mine || (o == mine && j < tid)) ? 1 : 0;
+          }
+          sorted[rk] = mine;
+        }
+        __syncthreads();
+        const int s_len = wg_prune<LPR, NCH>(g, sorted, cnt, (int)cap, L, evals);
+        if (tid < s_len) lk[tid] = L.S[tid];
+        cnt = s_len;
+        frozen = (s_len == (int)cap);
+        __syncthreads();
+      }
+    }
+    if ((u32)tid < cap) {
+      const bool on = tid < cnt;
+      ids[tid] = on ? (u32)(lk[tid] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[tid] = on ? __uint_as_float((u32)(lk[tid] >> 32)) : 0.f;
+    }
+    if (tid == 0) *cntp = (u32)cnt | (frozen ? 0x80000000u : 0u);
+    __syncthreads();
+  }
+  if ((tid & 63) == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
 }
 
 // D::distance for explicit pairs of stored items (tests / parity checks)
@@ -840,6 +1257,22 @@ struct PruneLauncher {
   }
 };
 template <int L, int C>
+struct PruneWgLauncher {
+  static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int grid, hipStream_t st) {
+    size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL);
+    hipLaunchKernelGGL((k_prune_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
+struct ApplyWgLauncher {
+  static hipError_t run(const GraphDev &g, const ApplyArgs &a, int SL, int grid, hipStream_t st) {
+    size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL);
+    hipLaunchKernelGGL((k_apply_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
 struct ApplyLauncher {
   static hipError_t run(const GraphDev &g, const ApplyArgs &a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((k_apply<L, C>), dim3(grid), dim3(64), 0, st, g, a);
@@ -871,6 +1304,14 @@ hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int 
 }
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<ApplyLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid,
+                         hipStream_t st) {
+  return dispatch_shape<PruneWgLauncher>(s, g, a, SL, grid, st);
+}
+hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
+                         hipStream_t st) {
+  return dispatch_shape<ApplyWgLauncher>(s, g, a, SL, grid, st);
 }
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st) {

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (counter_collection.csv) per kernel family into JSON.
+
+usage: pmc_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json
+HBM bytes as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced reads, so the read side
+is doubled; WRITE_SIZE is taken as is.  Separate passes (TCC slots: FETCH 3 + WRITE 2 > 4)."""
+import collections
+import csv
+import json
+import sys
+
+
+def family(name):
+    for k in ("k_walk", "k_prune_wg", "k_prune", "k_apply_wg", "k_apply", "k_emit", "k_segments"):
+        if k in name:
+            return k
+    return "radix_sort" if "rocprim" in name else "other"
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            f = family(r["Kernel_Name"])
+            agg[f][0] += 1
+            agg[f][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        n = max(f[k][0], w[k][0])
+        rd = 2.0 * f[k][1] * 1024
+        wr = w[k][1] * 1024
+        out[k] = {"launches": n, "fetch_size_kib": f[k][1], "write_size_kib": w[k][1],
+                  "hbm_read_bytes_corrected_x2": rd, "hbm_write_bytes": wr,
+                  "hbm_bytes_per_launch": (rd + wr) / max(n, 1)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:12s} launches {v['launches']:5d}  read {v['hbm_read_bytes_corrected_x2'] / 1e9:9.1f} GB"
+              f"  write {v['hbm_write_bytes'] / 1e9:8.1f} GB")
+
+
+if __name__ == "__main__":
+    main()
