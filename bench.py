@@ -178,7 +178,7 @@ def main():
                                f"{a.data} synthetic vectors resident in HBM, 1 step = 1 full build",
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
                    "batch_frac": builder.opts.batch_frac or 0.25,
-                   "batch_max": builder.opts.batch_max or 16384,
+                   "batch_max": builder.opts.batch_max or 32768,
                    "parallelism": f"item-sharded search x{world}, replicated graph"},
         "roofline": roof,
         "build": {"n_batches": int(graph.n_batches), "n_distance_evals": int(graph.n_distance_evals),

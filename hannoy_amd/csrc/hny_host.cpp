@@ -167,7 +167,8 @@ struct hny_builder {
   DevBuf<float> d_norms, d_l0_dist, d_up_dist;
   DevBuf<int> d_upper_idx;
   DevBuf<u32> d_l0_ids, d_l0_cnt, d_up_ids, d_up_cnt, d_order, d_eps, d_bits, d_vlog, d_cand_n,
-      d_seg_start, d_nseg, d_deferred;
+      d_seg_start, d_nseg, d_deferred, d_fin_cnt0, d_fin_cntu;
+  u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
   DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
   size_t sort_tmp_bytes = 0;
@@ -185,6 +186,10 @@ struct hny_builder {
   size_t ev_used = 0;
   bool profiling = false;
   ~hny_builder() {
+    if (h_l0) (void)hipHostFree(h_l0);
+    if (h_up) (void)hipHostFree(h_up);
+    if (h_cnt0) (void)hipHostFree(h_cnt0);
+    if (h_cntu) (void)hipHostFree(h_cntu);
     for (auto &e : evs) {
       (void)hipEventDestroy(e.a);
       (void)hipEventDestroy(e.b);
@@ -404,7 +409,7 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   b->n = (uint32_t)items->n;
   const uint32_t n = b->n;
   b->frac = o.batch_frac > 0.0 ? o.batch_frac : 0.25;
-  b->bmax = o.batch_max ? o.batch_max : 16384u;
+  b->bmax = o.batch_max ? o.batch_max : 32768u;
   uint32_t n16;
   int rc = pick_shape(o.metric, o.dim, b->shape, n16);
   if (rc) return rc;
@@ -511,6 +516,12 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   HIP_TRY(b->d_up_dist.alloc(nup * o.M));
   HIP_TRY(b->d_up_cnt.alloc(nup));
   HIP_TRY(b->d_order.alloc(nn));
+  HIP_TRY(b->d_fin_cnt0.alloc(nn));
+  HIP_TRY(b->d_fin_cntu.alloc(std::max<size_t>(nup, 1)));
+  HIP_TRY(hipHostMalloc((void **)&b->h_l0, nn * o.M0 * 4));
+  HIP_TRY(hipHostMalloc((void **)&b->h_cnt0, nn * 4));
+  HIP_TRY(hipHostMalloc((void **)&b->h_up, std::max<size_t>(nup * o.M, 1) * 4));
+  HIP_TRY(hipHostMalloc((void **)&b->h_cntu, std::max<size_t>(nup, 1) * 4));
   HIP_TRY(b->d_eps.alloc(HNY_MAX_EPS));
   HIP_TRY(b->d_stats.alloc(ST_COUNT));
   const uint32_t slots = std::min<uint32_t>(b->walk_slots, std::max<uint32_t>(b->max_batch, 256));
@@ -526,7 +537,7 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   HIP_TRY(b->d_vals_a.alloc(b->max_ops));
   HIP_TRY(b->d_vals_b.alloc(b->max_ops));
   HIP_TRY(b->d_seg_start.alloc(b->max_ops));
-  HIP_TRY(b->d_nseg.alloc(2));
+  HIP_TRY(b->d_nseg.alloc(4));
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, (u32)b->max_ops, st));
@@ -579,6 +590,7 @@ int hny_builder_reset(hny_builder *b) {
 int hny_builder_next_batch(hny_builder *b, hny_batch *out) {
   if (!b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
   if (b->in_batch) return fail(HNY_ERR_INVALID_ARG, "previous batch not applied");
+  if (b->finalized && b->pos < b->n) return fail(HNY_ERR_INVALID_ARG, "graph already finalised");
   memset(out, 0, sizeof *out);
   if (b->pos >= b->n) return HNY_OK;
   size_t gend = group_end(b, b->pos);
@@ -625,6 +637,8 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
+    w.queue = b->d_nseg.p + 2;
+    HIP_TRY(hipMemsetAsync(w.queue, 0, 4, b->stream));
     prof_begin(b, EV_WALK);
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
     prof_end(b);
@@ -735,9 +749,23 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER]);
-  std::vector<u32> l0((size_t)n * M0), up((size_t)b->n_upper * std::max(ml, 1u) * M);
-  if (n) HIP_TRY(hipMemcpy(l0.data(), b->d_l0_ids.p, l0.size() * 4, hipMemcpyDeviceToHost));
-  if (!up.empty()) HIP_TRY(hipMemcpy(up.data(), b->d_up_ids.p, up.size() * 4, hipMemcpyDeviceToHost));
+  // finalise every list on the device (sort + dedup), then copy through pinned staging
+  const size_t nup = (size_t)b->n_upper * std::max(ml, 1u);
+  if (!b->finalized) {
+    HIP_TRY(hnyk_finalize_lists(b->d_l0_ids.p, b->d_fin_cnt0.p, n, M0, b->stream));
+    HIP_TRY(hnyk_finalize_lists(b->d_up_ids.p, b->d_fin_cntu.p, (u32)nup, M, b->stream));
+    b->finalized = true;
+  }
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(b->h_l0, b->d_l0_ids.p, (size_t)n * M0 * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_cnt0, b->d_fin_cnt0.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+  }
+  if (nup) {
+    HIP_TRY(hipMemcpyAsync(b->h_up, b->d_up_ids.p, nup * M * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_cntu, b->d_fin_cntu.p, nup * 4, hipMemcpyDeviceToHost, b->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const u32 *l0 = b->h_l0, *up = b->h_up;
 
   // every inserted item owns a (possibly empty) record on layers 0..=level (add_in_layers_below,
   // hnsw.rs:419-424)
@@ -748,9 +776,14 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   uint32_t *rec_item = (uint32_t *)malloc(std::max<uint64_t>(nrec, 1) * 4);
   uint8_t *rec_layer = (uint8_t *)malloc(std::max<uint64_t>(nrec, 1));
   uint64_t *rec_off = (uint64_t *)malloc((nrec + 1) * 8);
-  std::vector<uint32_t> cnt(nrec, 0);
-  std::vector<uint32_t> tmp((size_t)nrec * std::max(M0, M));
-  const size_t tw = std::max(M0, M);
+  rec_off[0] = 0;
+  for (uint32_t s = 0; s < n; s++) // offsets: sequential prefix over the device-computed counts
+    for (uint32_t l = 0; l <= b->level[s]; l++) {
+      uint64_t r = rec_first[s] + l;
+      uint32_t c = l == 0 ? b->h_cnt0[s] : b->h_cntu[(size_t)b->upper_idx[s] * ml + (l - 1)];
+      rec_off[r + 1] = rec_off[r] + c;
+    }
+  uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (n < 10000) nt = 1;
   auto work = [&](uint32_t lo, uint32_t hi) {
@@ -761,11 +794,9 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
         rec_layer[r] = (uint8_t)l;
         const u32 *src = l == 0 ? &l0[(size_t)s * M0]
                                 : &up[((size_t)b->upper_idx[s] * ml + (l - 1)) * M];
-        uint32_t cap = l == 0 ? M0 : M, c = 0;
-        uint32_t *dst = &tmp[r * tw];
-        for (uint32_t k = 0; k < cap && src[k] != HNY_SENT; k++) dst[c++] = b->ids[src[k]];
-        std::sort(dst, dst + c);
-        cnt[r] = (uint32_t)(std::unique(dst, dst + c) - dst); // RoaringBitmap::from_iter
+        uint32_t c = (uint32_t)(rec_off[r + 1] - rec_off[r]);
+        uint32_t *dst = nbrs + rec_off[r];
+        for (uint32_t k = 0; k < c; k++) dst[k] = b->ids[src[k]]; // slot -> item id (order kept)
       }
   };
   {
@@ -774,10 +805,6 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
       th.emplace_back(work, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt));
     for (auto &t : th) t.join();
   }
-  rec_off[0] = 0;
-  for (uint64_t r = 0; r < nrec; r++) rec_off[r + 1] = rec_off[r] + cnt[r];
-  uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
-  for (uint64_t r = 0; r < nrec; r++) memcpy(nbrs + rec_off[r], &tmp[r * tw], (size_t)cnt[r] * 4);
   uint32_t *eps = (uint32_t *)malloc(std::max<size_t>(b->entry_points.size(), 1) * 4);
   for (size_t i = 0; i < b->entry_points.size(); i++) eps[i] = b->ids[b->entry_points[i]];
   g->n_records = nrec;
@@ -883,6 +910,12 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     for (uint64_t i = 0; i < nq; i++) out_counts[i] = 0; // reader.rs:652-654
     return HNY_OK;
   }
+  if (!b->finalized) { // Reader::visit iterates Links bitmaps: ascending, deduplicated
+    HIP_TRY(hnyk_finalize_lists(b->d_l0_ids.p, b->d_fin_cnt0.p, b->n, b->o.M0, b->stream));
+    HIP_TRY(hnyk_finalize_lists(b->d_up_ids.p, b->d_fin_cntu.p,
+                                (u32)((size_t)b->n_upper * std::max(b->max_level, 1u)), b->o.M, b->stream));
+    b->finalized = true;
+  }
   uint32_t rcap = 64;
   while (rcap < std::max<uint32_t>(ef, (uint32_t)b->entry_points.size()) + 1) rcap *= 2;
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
@@ -928,6 +961,8 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
+    w.queue = b->d_nseg.p + 2;
+    HIP_TRY(hipMemsetAsync(w.queue, 0, 4, b->stream));
     HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(cnt, b->walk_slots), b->stream));
     HIP_TRY(hipMemcpyAsync(hc.data(), dcand.p, (size_t)cnt * rcap * 8, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));

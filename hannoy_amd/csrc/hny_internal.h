@@ -80,6 +80,7 @@ struct WalkArgs {
   u32 bits_words;
   u32 *vlog;        // [grid][log_cap]
   u32 log_cap;
+  u32 *queue;       // work counter, zeroed before the launch
 };
 
 struct PruneArgs {
@@ -133,4 +134,5 @@ hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *ke
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st);
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);
+hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st);
 size_t hnyk_walk_lds_bytes(u32 rcap);

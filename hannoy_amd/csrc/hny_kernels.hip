@@ -650,7 +650,12 @@ __global__ __launch_bounds__(64, HNY_WALK_WPE) void k_walk(GraphDev g, WalkArgs 
   u64 evals = 0;
   u32 err_iter = 0, log_over_cnt = 0;
 
-  for (u32 m = a.lo + blockIdx.x; m < a.hi; m += gridDim.x) {
+  // dynamic work queue: queries differ a lot in length, a static stride leaves a long launch tail
+  for (;;) {
+    u32 m = 0;
+    if (ln == 0) m = a.lo + atomicAdd(a.queue, 1u);
+    m = uni(m);
+    if (m >= a.hi) break;
     const unsigned char *qrow;
     float qn = 0.f;
     if (a.q_rows) {
@@ -1217,6 +1222,34 @@ __global__ __launch_bounds__(64) void k_pair_distances(GraphDev g, const u32 *pa
   }
 }
 
+// Links record of one node = RoaringBitmap::from_iter(list ids) (hnsw.rs:204-208): ascending,
+// deduplicated (slot order == id order).  One wave per list, in place: rank among the first
+// occurrences by broadcast compare.  This is also the order Reader::visit iterates a Links bitmap
+// in (reader.rs:343-346), so the k-NN search runs on the finalised lists.
+__global__ __launch_bounds__(64) void k_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap) {
+  __shared__ u32 sh[64];
+  __shared__ u32 fst[64];
+  const int ln = threadIdx.x;
+  for (u32 li = blockIdx.x; li < n_lists; li += gridDim.x) {
+    u32 *row = ids + (size_t)li * cap;
+    const u32 v = (u32)ln < cap ? row[ln] : HNY_SENT;
+    sh[ln] = v;
+    WSYNC();
+    bool first = v != HNY_SENT;
+    for (int j = 0; j < ln; j++) first = first && sh[j] != v;
+    fst[ln] = first ? 1u : 0u;
+    WSYNC();
+    int pos = 0;
+    for (u32 j = 0; j < cap; j++) pos += (fst[j] != 0u && sh[j] < v) ? 1 : 0;
+    const u64 keep = __ballot(first);
+    if ((u32)ln < cap) row[ln] = HNY_SENT;
+    WSYNC();
+    if (first) row[pos] = v;
+    if (ln == 0) cnt_out[li] = (u32)__popcll(keep);
+    WSYNC();
+  }
+}
+
 __global__ void k_fill_u32(u32 *p, u32 v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1327,6 +1360,12 @@ hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg,
   if (!n_ops) return hipSuccess;
   hipLaunchKernelGGL(k_segments, dim3((n_ops + 255) / 256), dim3(256), 0, st, keys, n_ops, seg_start,
                      n_seg);
+  return hipGetLastError();
+}
+hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st) {
+  if (!n_lists) return hipSuccess;
+  unsigned grid = n_lists < 65536u * 4u ? n_lists : 65536u * 4u;
+  hipLaunchKernelGGL(k_finalize_lists, dim3(grid), dim3(64), 0, st, ids, cnt_out, n_lists, cap);
   return hipGetLastError();
 }
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st) {

@@ -97,3 +97,58 @@ def test_build_equals_oracle_bit_exact(orc, hny, metric, n, dim, M, M0, ef, frac
     assert g.n_tie_pool_overflow == 0
     _same_graph(g, o)
     assert g.n_links_added == o.n_links_added
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 3000, 96, 8, 16, 48), (1, 2000, 40, 6, 12, 32),
+                                                   (3, 3000, 256, 8, 16, 32)])
+def test_knn_search_equals_oracle_reader(orc, hny, metric, n, dim, M, M0, ef):
+    """hny_builder_search_knn == restated Reader::nns().by_vector on the same graph: same ids, same
+    distances (bit for bit in the wave order)."""
+    rng = np.random.default_rng(n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    qs = rng.uniform(-1, 1, (200, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=5))
+    qc = orc.encode_vectors(metric, qs)
+    qh = orc.make_headers(metric, dim, qc)
+    with hny.Builder(items, M=M, M0=M0, ef_construction=ef, batch_frac=0.1, batch_max=128) as b:
+        b.run()
+        g = b.finish()
+        ids, dists, counts = b.search_knn(qc, qh, k=10, ef_search=50)
+        # rebuilding after reset() gives the same graph (vectors stay resident)
+        b.reset()
+        b.run()
+        g2 = b.finish()
+    _same_graph(g2, g)
+    oids, odists, ocounts = orc.search(ds, g, qc, qh, k=10, ef_search=50, order=orc.ORDER_WAVE)
+    assert np.array_equal(counts, ocounts)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(dists.view(np.uint32), odists.view(np.uint32))
+
+
+def test_non_contiguous_ids_and_tiny_inputs(orc, hny):
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 3, 17):
+        vecs = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        ids = np.sort(rng.choice(2 ** 32 - 1, n, replace=False)).astype(np.uint32)
+        levels = draw_levels(n, 4, seed=n)
+        ds = orc.Dataset.from_f32(orc.EUCLIDEAN, vecs, levels, ids)
+        items = hny.ItemSet(hny.EUCLIDEAN, 12, ds.ids, ds.codes, ds.headers, ds.levels)
+        o = orc.build(ds, M=4, M0=8, ef=16, order=orc.ORDER_WAVE, batch_frac=0.5, batch_max=4)
+        g = hny.build(items, M=4, M0=8, ef_construction=16, batch_frac=0.5, batch_max=4)
+        _same_graph(g, o)
+    # empty item set: no records, no entry points
+    e = hny.ItemSet(hny.COSINE, 8, np.zeros(0, np.uint32), np.zeros((0, 32), np.uint8),
+                    np.zeros((0, 4), np.uint8))
+    g = hny.build(e)
+    assert len(g.rec_item) == 0 and len(g.entry_points) == 0
+
+
+def test_cancel_and_progress(hny):
+    rng = np.random.default_rng(2)
+    vecs = rng.uniform(-1, 1, (3000, 16)).astype(np.float32)
+    items = hny.ItemSet.from_f32(hny.EUCLIDEAN, vecs)
+    seen = []
+    hny.build(items, M=8, M0=16, ef_construction=32, progress=lambda d, t: seen.append((d, t)))
+    assert seen and seen[-1] == (3000, 3000) and all(a[0] <= b[0] for a, b in zip(seen, seen[1:]))
+    with pytest.raises(hny.BuildCancelled):
+        hny.build(items, M=8, M0=16, ef_construction=32, cancel=lambda: True)
