@@ -30,7 +30,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=1_000_000)
+    p.add_argument("--items", "--n", dest="n", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--metric", default="cosine", choices=["cosine", "euclidean", "manhattan", "hamming"])
     p.add_argument("--M", type=int, default=16)
@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-recall", action="store_true")
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo: test mode, ranks may share one GPU, exchange staged through the host")
     return p.parse_args()
 
 
@@ -98,10 +100,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     import hannoy_amd as H
     from hannoy_amd import multigpu
     H.load_library()
@@ -128,7 +134,8 @@ def main():
     builder = H.Builder(items, M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed,
                         batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank)
     builder.set_profiling(True)
-    driver = multigpu.Driver(builder, torch, dist if world > 1 else None, rank, world, dev)
+    driver = multigpu.Driver(builder, torch, dist if world > 1 else None, rank, world, dev,
+                             host_staged=(a.backend == "gloo"))
 
     def step():
         builder.reset()
@@ -149,7 +156,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if graph is None:
@@ -233,6 +240,13 @@ def main():
                                             threads=cores)[0::2], truth_s)
             out["recall_parity_on_sample"] = {"n": ns, "cpu_built": round(r_cpu, 4),
                                               "gpu_built": round(r_gpu, 4)}
+    if world > 1:  # replicas must be bit-identical: compare a checksum of the exported graph
+        import zlib
+        cs = zlib.crc32(graph.nbrs.tobytes()) ^ zlib.crc32(graph.offsets.tobytes())
+        tc = torch.tensor([cs, -cs], dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        out["replicas_identical"] = bool(tc[0].item() == cs and -tc[1].item() == cs)
+        out["n_collectives"] = driver.n_collectives
     if rank == 0:
         print(json.dumps(out), flush=True)
     builder.close()

@@ -10,8 +10,11 @@ import math
 
 
 class Driver:
-    def __init__(self, builder, torch, dist, rank=0, world=1, device=None, min_shard_batch=None):
+    def __init__(self, builder, torch, dist, rank=0, world=1, device=None, min_shard_batch=None,
+                 host_staged=False):
         self.b, self.torch, self.dist = builder, torch, dist
+        # host_staged: exchange through host memory (gloo); default is device buffers over RCCL
+        self.host_staged = host_staged
         self.rank, self.world, self.device = rank, world, device
         self.min_shard = 64 * world if min_shard_batch is None else min_shard_batch
         self._buf = None
@@ -49,7 +52,12 @@ class Driver:
             b.search(lo, hi, full.data_ptr())
             b.sync()  # the builder runs on its own HIP stream
             mine = full[self.rank * per * stride:(self.rank + 1) * per * stride].clone()
-            self.dist.all_gather_into_tensor(full[:self.world * per * stride], mine)
+            if self.host_staged:
+                gathered = self.torch.empty(self.world * per * stride, dtype=self.torch.int64)
+                self.dist.all_gather_into_tensor(gathered, mine.cpu())
+                full[:self.world * per * stride].copy_(gathered)
+            else:
+                self.dist.all_gather_into_tensor(full[:self.world * per * stride], mine)
             self.n_collectives += 1
             self._sync_collective()
             b.apply(full.data_ptr())
