@@ -408,6 +408,11 @@ struct Builder {
   std::vector<std::vector<uint32_t>> owner;         /* [layer][list index] -> slot */
   std::atomic<uint64_t> n_evals{0}, n_links{0};
   bool threaded = false;
+  /* incremental builds only (Appendix B of SURVEY.md): the previous graph as stored in LMDB */
+  bool incremental = false;
+  std::vector<std::vector<std::vector<uint32_t>>> disk; /* [layer][slot] -> old Links ids (ascending) */
+  std::vector<std::vector<uint8_t>> has_disk;           /* [layer][slot] a Links record exists */
+  std::vector<uint8_t> has_vec;                         /* slot still has an Item record */
 
   const uint8_t *vec(uint32_t s) const { return (const uint8_t *)it.vectors + (size_t)s * it.stride; }
   const uint8_t *hdr(uint32_t s) const {
@@ -493,15 +498,20 @@ void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint3
     if (f > f_max) break;       /* raw f32 compare :485 */
     uint32_t c = cand.top().id;
     cand.pop();
-    /* get_neighbours :428-456 — fresh DB: no on-disk links, in-memory list in insertion order */
+    /* get_neighbours :428-456 — on-disk Links (ascending ids) first, then the in-memory list in
+     * insertion order; an absent in-memory entry is created lazily (:449-452) */
     S.nbuf.clear();
+    if (B.incremental && layer < B.disk.size() && B.has_disk[layer][c])
+      for (uint32_t p : B.disk[layer][c]) S.nbuf.push_back(p);
     if (NodeList *nl = B.list(layer, c)) {
       B.lock(nl);
+      if (B.incremental) nl->present.store(1, std::memory_order_relaxed);
       for (const Link &l : nl->links) S.nbuf.push_back(l.id);
       B.unlock(nl);
     }
     for (uint32_t p : S.nbuf) {
       if (!S.visit(p)) continue; /* :493 */
+      if (B.incremental && !B.has_vec[p]) continue; /* MissingKey => deleted item, :498-502 */
       float d = qd(p, S.evals);  /* :503 */
       if (res.size() < ef || d < f_max) { /* :505, f_max captured once per pop */
         Link l{d, p};
@@ -873,6 +883,228 @@ int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
       g->offsets.push_back(g->nbrs.size());
     }
   g->n_evals = evals;
+  g->n_links = links;
+  *out = g.release();
+  return 0;
+}
+
+/* Incremental build — Appendix B of SURVEY.md, validated against KAT-2/3/4. */
+int orc_build_incremental(const orc_opts *opts, const orc_items *items, const uint32_t *to_insert,
+                          uint64_t n_insert, const uint8_t *insert_levels, const uint32_t *to_delete,
+                          uint64_t n_delete, const orc_prev_graph *prev, orc_graph **out) {
+  if (!opts || !items || !prev || !out) return -1;
+  /* universe of ids = current items U deleted items U everything the old graph mentions */
+  std::vector<uint32_t> U(items->ids, items->ids + items->n);
+  U.insert(U.end(), to_delete, to_delete + n_delete);
+  U.insert(U.end(), prev->rec_item, prev->rec_item + prev->n_records);
+  if (prev->n_records) U.insert(U.end(), prev->nbrs, prev->nbrs + prev->offsets[prev->n_records]);
+  U.insert(U.end(), prev->entry_points, prev->entry_points + prev->n_entry_points);
+  std::sort(U.begin(), U.end());
+  U.erase(std::unique(U.begin(), U.end()), U.end());
+  const uint32_t n = (uint32_t)U.size();
+  auto slot = [&](uint32_t id) { return (uint32_t)(std::lower_bound(U.begin(), U.end(), id) - U.begin()); };
+
+  Builder B;
+  B.o = *opts;
+  B.dist = Dist{opts->metric, opts->order, opts->dim, vec_bytes(opts->metric, opts->dim)};
+  B.n = n;
+  B.incremental = true;
+  const size_t vb = B.dist.vbytes, hb = items->header_size;
+  std::vector<uint8_t> vecs((size_t)n * vb, 0), hdrs((size_t)n * hb, 0);
+  B.has_vec.assign(n, 0);
+  for (uint64_t i = 0; i < items->n; i++) {
+    uint32_t s = slot(items->ids[i]);
+    std::memcpy(&vecs[(size_t)s * vb], (const uint8_t *)items->vectors + i * items->stride, vb);
+    std::memcpy(&hdrs[(size_t)s * hb], (const uint8_t *)items->headers + i * hb, hb);
+    B.has_vec[s] = 1;
+  }
+  B.it.n = n;
+  B.it.ids = U.data();
+  B.it.vectors = vecs.data();
+  B.it.stride = vb;
+  B.it.headers = hdrs.data();
+  B.it.header_size = hb;
+  std::vector<uint8_t> del(n, 0);
+  for (uint64_t i = 0; i < n_delete; i++) del[slot(to_delete[i])] = 1;
+
+  /* the previous graph as LMDB holds it */
+  const uint32_t MAXL = 8;
+  B.disk.assign(MAXL, std::vector<std::vector<uint32_t>>(n));
+  B.has_disk.assign(MAXL, std::vector<uint8_t>(n, 0));
+  for (uint64_t r = 0; r < prev->n_records; r++) {
+    uint32_t l = prev->rec_layer[r], s = slot(prev->rec_item[r]);
+    if (l >= MAXL) return -2;
+    B.has_disk[l][s] = 1;
+    for (uint64_t j = prev->offsets[r]; j < prev->offsets[r + 1]; j++)
+      B.disk[l][s].push_back(slot(prev->nbrs[j]));
+  }
+  /* storage for every (layer, slot); B.idx.size() is the number of layers that "exist"
+   * (self.layers.len()) */
+  std::vector<std::vector<int32_t>> all_idx(MAXL, std::vector<int32_t>(n));
+  std::vector<std::unique_ptr<NodeList[]>> all_lists(MAXL);
+  for (uint32_t l = 0; l < MAXL; l++) {
+    for (uint32_t s = 0; s < n; s++) all_idx[l][s] = (int32_t)s;
+    all_lists[l] = std::unique_ptr<NodeList[]>(new NodeList[n]);
+  }
+  B.lists = std::move(all_lists);
+  auto set_layers = [&](uint32_t count) {
+    B.idx.assign(all_idx.begin(), all_idx.begin() + count);
+  };
+
+  /* hnsw.rs:141-149: one level per to_insert item, ascending id */
+  std::vector<std::pair<uint32_t, uint32_t>> levels; /* (slot, level) */
+  uint32_t cur_max_level = 0;
+  for (uint64_t i = 0; i < n_insert; i++) {
+    levels.push_back({slot(to_insert[i]), insert_levels[i]});
+    cur_max_level = std::max<uint32_t>(cur_max_level, insert_levels[i]);
+  }
+  /* prepare_levels_and_entry_points, hnsw.rs:236-289 */
+  uint32_t max_level = prev->max_level;
+  std::vector<uint8_t> in_new(n, 0), in_old(n, 0);
+  uint32_t n_old = 0, n_new = 0;
+  std::vector<uint32_t> del_eps;
+  for (uint32_t i = 0; i < prev->n_entry_points; i++) {
+    uint32_t s = slot(prev->entry_points[i]);
+    if (!in_old[s]) { in_old[s] = 1; n_old++; }
+    if (del[s]) del_eps.push_back(s);
+    else if (!in_new[s]) { in_new[s] = 1; n_new++; }
+  }
+  {
+    uint32_t l = max_level;
+    for (size_t k = 0; k < del_eps.size(); k++) {
+      for (;;) {
+        if (l < MAXL)
+          for (uint32_t s = 0; s < n; s++) { /* iter_layer_links(l): ascending item */
+            if (!B.has_disk[l][s]) continue;
+            if (!del[s] && !in_new[s]) { /* new_eps.insert(item) returned true */
+              in_new[s] = 1;
+              n_new++;
+              break;
+            }
+          }
+        if (l == 0) break; /* checked_sub */
+        l -= 1;
+      }
+    }
+  }
+  if (!del_eps.empty() && n_new != n_old) max_level = 0; /* :261-263 */
+  for (uint32_t s = 0; s < n; s++)
+    if (in_new[s]) levels.push_back({s, max_level}); /* :267 re-index the old entry points */
+  std::stable_sort(levels.begin(), levels.end(),
+                   [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
+                     return a.second > b.second;
+                   }); /* :268 (unstable in Rust; stable == what small inputs get) */
+  if (cur_max_level > max_level) { /* :272-276 */
+    std::fill(in_new.begin(), in_new.end(), 0);
+    max_level = cur_max_level;
+  }
+  B.max_level = max_level;
+  set_layers(max_level + 1); /* :279-281 */
+  for (auto &pr : levels) {  /* :278, :282-285 upper_layer = take_while(level == max_level) */
+    if (pr.second != max_level) break;
+    in_new[pr.first] = 1;
+    register_item(B, pr.first, max_level);
+  }
+  for (uint32_t s = 0; s < n; s++)
+    if (in_new[s]) B.entry_points.push_back(s); /* :287 */
+
+  /* hnsw.rs:172-185 with one thread */
+  Scratch S;
+  uint64_t links = 0;
+  for (auto &pr : levels) {
+    uint32_t q = pr.first, lvl = pr.second;
+    std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end());
+    auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
+    std::vector<Link> res, sel;
+    for (uint32_t l = B.max_level; l > lvl; l--) {
+      walk_layer(B, S, qd, eps, l, 1, res);
+      eps.assign(1, res.front().id);
+    }
+    register_item(B, q, lvl); /* :309 */
+    for (int32_t l = (int32_t)lvl; l >= 0; l--) {
+      walk_layer(B, S, qd, eps, (uint32_t)l, B.o.ef_construction, res);
+      robust_prune(B, res, B.cap(lvl), S.evals, sel);
+      eps.clear();
+      for (const Link &sl : sel) {
+        add_link(B, q, sl, (uint32_t)l, S.evals);
+        add_link(B, sl.id, Link{sl.d, q}, (uint32_t)l, S.evals);
+        eps.push_back(sl.id);
+        links += 2;
+      }
+    }
+  }
+
+  /* fill_gaps_from_deleted, hnsw.rs:334-415 */
+  {
+    uint32_t need = (uint32_t)B.idx.size();
+    for (uint32_t l = 0; l < MAXL; l++)
+      for (uint32_t s = 0; s < n; s++)
+        if (B.has_disk[l][s]) need = std::max(need, l + 1); /* :352-354 resize layers */
+    set_layers(need);
+    for (uint32_t s = 0; s < n; s++)      /* iter_links: key order (item, layer) */
+      for (uint32_t l = 0; l < MAXL; l++) {
+        if (!B.has_disk[l][s] || del[s]) continue; /* :373-375 */
+        NodeList *nl = B.list(l, s);
+        std::vector<Link> new_links;
+        if (nl->present.load()) new_links = nl->links; /* map_guard.get(&id) */
+        std::vector<uint8_t> inbm(n, 0);
+        for (uint32_t x : B.disk[l][s])
+          if (del[x] && B.has_disk[l][x]) /* lmdb.links(x, lvl).unwrap_or_default() */
+            for (uint32_t y : B.disk[l][x]) inbm[y] = 1;
+        for (uint32_t x : B.disk[l][s]) inbm[x] = 1; /* bitmap |= links */
+        std::vector<uint32_t> bm;
+        for (uint32_t y = 0; y < n; y++)
+          if (inbm[y] && !del[y]) bm.push_back(y); /* bitmap -= to_delete */
+        uint32_t thresh = B.cap(l);
+        if (bm.size() + new_links.size() <= thresh) { /* :392-400 */
+          std::vector<Link> entries;
+          for (uint32_t y : bm) entries.push_back(Link{0.0f, y});
+          entries.insert(entries.end(), new_links.begin(), new_links.end());
+          nl->links.swap(entries);
+          nl->present.store(1);
+          continue;
+        }
+        for (uint32_t y : bm) new_links.push_back(Link{B.d_items(s, y, S.evals), y}); /* :403-408 */
+        std::vector<Link> pruned;
+        robust_prune(B, new_links, B.cap(l), S.evals, pruned);
+        nl->links.swap(pruned);
+        nl->present.store(1);
+      }
+  }
+
+  /* DB after the build: old records, overwritten by every in-memory key (hnsw.rs:195-213), minus
+   * the Links of deleted items (writer.rs:580, 692-718) */
+  auto g = std::make_unique<orc_graph>();
+  g->max_level = B.max_level;
+  for (uint32_t s : B.entry_points) g->entry_points.push_back(U[s]);
+  g->offsets.push_back(0);
+  g->raw_offsets.push_back(0);
+  std::vector<uint32_t> tmp;
+  for (uint32_t s = 0; s < n; s++)
+    for (uint32_t l = 0; l < MAXL; l++) {
+      if (del[s]) continue;
+      NodeList *nl = l < B.idx.size() ? B.list(l, s) : nullptr;
+      bool mem = nl && nl->present.load();
+      if (!mem && !B.has_disk[l][s]) continue;
+      g->rec_item.push_back(U[s]);
+      g->rec_layer.push_back((uint8_t)l);
+      tmp.clear();
+      if (mem) {
+        for (const Link &k : nl->links) {
+          tmp.push_back(U[k.id]);
+          g->raw_nbrs.push_back(U[k.id]);
+          g->raw_dists.push_back(k.d);
+        }
+      } else {
+        for (uint32_t y : B.disk[l][s]) tmp.push_back(U[y]);
+      }
+      g->raw_offsets.push_back(g->raw_nbrs.size());
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      g->nbrs.insert(g->nbrs.end(), tmp.begin(), tmp.end());
+      g->offsets.push_back(g->nbrs.size());
+    }
+  g->n_evals = S.evals;
   g->n_links = links;
   *out = g.release();
   return 0;

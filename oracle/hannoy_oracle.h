@@ -98,6 +98,26 @@ uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap);
 /* ---- build (hnsw.rs:122-216, fresh DB) ---- */
 int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out);
 void orc_graph_free(orc_graph *g);
+
+/* ---- incremental build (hnsw.rs:122-216 on a non-empty DB: prepare_levels_and_entry_points
+ * :236-289 deletion branch, get_neighbours :438-441 on-disk links, fill_gaps_from_deleted :334-415,
+ * Writer::build set algebra writer.rs:539-554 + delete_links_from_db :692-718).  `items` = every
+ * item that exists AFTER the update (deleted ones removed, overwritten ones with their new
+ * vector); `prev` = the Links records / entry points / max_level stored by the previous build.
+ * Sequential (1 thread).  The result is the complete DB state after the build. ---- */
+typedef struct {
+  uint64_t n_records;
+  const uint32_t *rec_item;
+  const uint8_t *rec_layer;
+  const uint64_t *offsets;
+  const uint32_t *nbrs;
+  const uint32_t *entry_points;
+  uint32_t n_entry_points;
+  uint32_t max_level;
+} orc_prev_graph;
+int orc_build_incremental(const orc_opts *opts, const orc_items *items, const uint32_t *to_insert,
+                          uint64_t n_insert, const uint8_t *insert_levels, const uint32_t *to_delete,
+                          uint64_t n_delete, const orc_prev_graph *prev, orc_graph **out);
 uint64_t orc_graph_n_records(const orc_graph *g);
 uint64_t orc_graph_n_links(const orc_graph *g); /* total ids over all records (deduplicated) */
 /* records sorted by (item id, layer); offsets has n_records+1 entries; neighbours are item ids

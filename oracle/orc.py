@@ -37,6 +37,12 @@ class Items(C.Structure):
                 ("levels", C.c_void_p)]
 
 
+class PrevGraph(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("rec_item", C.c_void_p), ("rec_layer", C.c_void_p),
+                ("offsets", C.c_void_p), ("nbrs", C.c_void_p), ("entry_points", C.c_void_p),
+                ("n_entry_points", C.c_uint32), ("max_level", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -64,6 +70,10 @@ def lib():
         L.orc_build.restype = C.c_int
         L.orc_build.argtypes = [C.POINTER(Opts), C.POINTER(Items), C.POINTER(C.c_void_p)]
         L.orc_graph_free.argtypes = [C.c_void_p]
+        L.orc_build_incremental.restype = C.c_int
+        L.orc_build_incremental.argtypes = [C.POINTER(Opts), C.POINTER(Items), C.c_void_p,
+                                            C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                            C.POINTER(PrevGraph), C.POINTER(C.c_void_p)]
         for name in ("orc_graph_n_records", "orc_graph_n_links", "orc_graph_n_raw",
                      "orc_graph_distance_evals", "orc_graph_links_added"):
             getattr(L, name).restype = C.c_uint64
@@ -249,6 +259,29 @@ def build(ds, **kw):
     rc = lib().orc_build(C.byref(o), C.byref(it), C.byref(h))
     if rc != 0:
         raise RuntimeError(f"orc_build failed: {rc}")
+    g = Graph(h)
+    g.opts = o
+    return g
+
+
+def build_incremental(ds, prev, to_insert, insert_levels, to_delete, **kw):
+    """ds: items that exist after the update; prev: graph of the previous build."""
+    o = make_opts(ds.metric, ds.dim, **kw)
+    it = ds.items_struct()
+    ins = np.ascontiguousarray(to_insert, np.uint32)
+    lv = np.ascontiguousarray(insert_levels, np.uint8)
+    dl = np.ascontiguousarray(to_delete, np.uint32)
+    keep = [np.ascontiguousarray(prev.rec_item, np.uint32), np.ascontiguousarray(prev.rec_layer, np.uint8),
+            np.ascontiguousarray(prev.offsets, np.uint64),
+            np.ascontiguousarray(prev.nbrs if len(prev.nbrs) else np.zeros(1), np.uint32),
+            np.ascontiguousarray(prev.entry_points, np.uint32)]
+    pg = PrevGraph(len(keep[0]), _p(keep[0]).value, _p(keep[1]).value, _p(keep[2]).value,
+                   _p(keep[3]).value, _p(keep[4]).value, len(keep[4]), int(prev.max_level))
+    h = C.c_void_p()
+    rc = lib().orc_build_incremental(C.byref(o), C.byref(it), _p(ins), len(ins), _p(lv), _p(dl),
+                                     len(dl), C.byref(pg), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"orc_build_incremental failed: {rc}")
     g = Graph(h)
     g.opts = o
     return g

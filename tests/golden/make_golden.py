@@ -5,6 +5,8 @@ LMDB), so these known-answer vectors are DATA transcribed from the reference's
 own test expectations (inputs + expected outputs), not outputs of running it:
 
   KAT-1  /root/reference/src/tests/writer.rs:376-408 (== 589-622)   fresh build snapshot
+  KAT-2  /root/reference/src/tests/writer.rs:410-437                overwrite one item, rebuild
+  KAT-3/4 /root/reference/src/tests/writer.rs:624-677               delete item 3, then item 1
   KAT-5  /root/reference/src/tests/writer.rs:67-128, 562-570        single-item builds
   KAT-6  /root/reference/src/unaligned_vector/binary_quantized_test.rs:11-27,100-167
          /root/reference/src/unaligned_vector/binary_test.rs:11-64   quantiser bit patterns
@@ -30,6 +32,28 @@ kat["kat1"] = {
     "links": [  # [item, layer, [neighbours]] in LMDB key order (item, layer)
         [0, 0, [1, 2]], [0, 1, [2]], [1, 0, [0, 2]], [2, 0, [0, 1, 3]], [2, 1, [0, 3]],
         [3, 0, [2, 4]], [3, 1, [2]], [4, 0, [3, 5]], [5, 0, [4]]],
+}
+
+# incremental builds on top of KAT-1's DB (same M = M0 = 3, efC = 100)
+kat["kat2"] = {
+    "source": "src/tests/writer.rs:410-437 (overwrite_one_item_incremental, second snapshot)",
+    "overwrite": {"id": 3, "vector": [6.0, 0.0]}, "to_insert": [3], "to_delete": [],
+    "insert_levels_any_of": [[0], [1]],
+    "entry_points": [0, 2, 3], "max_level": 1,
+    "links": [[0, 0, [1, 2]], [0, 1, [2]], [1, 0, [0, 2]], [2, 0, [1, 4]], [2, 1, [0, 3]],
+              [3, 0, [5]], [3, 1, [2]], [4, 0, [2, 3, 5]], [5, 0, [3, 4]]],
+}
+kat["kat3"] = {
+    "source": "src/tests/writer.rs:624-650 (delete_one_item, second snapshot)",
+    "to_insert": [], "to_delete": [3], "entry_points": [0, 1, 2], "max_level": 1,
+    "links": [[0, 0, [1]], [0, 1, [1, 2]], [1, 0, [0, 2]], [1, 1, [0, 2]], [2, 0, [1, 2, 4]],
+              [2, 1, [1, 2]], [4, 0, [2, 4, 5]], [5, 0, [4]]],
+}
+kat["kat4"] = {
+    "source": "src/tests/writer.rs:652-677 (delete_one_item, third snapshot; applied after kat3)",
+    "to_insert": [], "to_delete": [1], "entry_points": [0, 2, 4], "max_level": 1,
+    "links": [[0, 0, [0, 2]], [0, 1, [0, 2]], [2, 0, [0, 2, 4]], [2, 1, [0, 2, 4]],
+              [4, 0, [2, 4, 5]], [4, 1, [2]], [5, 0, [4]]],
 }
 
 kat["kat5"] = [

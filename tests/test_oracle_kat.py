@@ -124,3 +124,35 @@ def test_level_probas(orc):
     assert len(p) == 8
     assert abs(p[0] - 15 / 16) < 1e-6 and abs(p[1] - 15 / 256) < 1e-6
     assert len(orc.level_probas(32)) == 6
+
+
+def test_kat2_3_4_incremental_builds(kat, orc):
+    """Incremental path (prepare_levels_and_entry_points deletion branch, on-disk links in
+    get_neighbours, fill_gaps_from_deleted) against the reference's snapshots."""
+    k1 = kat["kat1"]
+    v = np.array(k1["vectors"], np.float32)
+    ds1 = orc.Dataset.from_f32(orc.EUCLIDEAN, v, k1["levels"])
+    g1 = orc.build(ds1, M=3, M0=3, ef=100)
+    # KAT-2: overwrite item 3 with [6, 0]
+    k2 = kat["kat2"]
+    v2 = v.copy()
+    v2[k2["overwrite"]["id"]] = k2["overwrite"]["vector"]
+    ds2 = orc.Dataset.from_f32(orc.EUCLIDEAN, v2, np.zeros(6, np.uint8))
+    for lv in k2["insert_levels_any_of"]:
+        g2 = orc.build_incremental(ds2, g1, k2["to_insert"], lv, k2["to_delete"], M=3, M0=3, ef=100)
+        assert g2.entry_points.tolist() == k2["entry_points"] and g2.max_level == k2["max_level"]
+        assert _links_of(g2) == k2["links"]
+    # KAT-3: delete item 3 from the KAT-1 DB
+    k3 = kat["kat3"]
+    keep = [0, 1, 2, 4, 5]
+    ds3 = orc.Dataset.from_f32(orc.EUCLIDEAN, v[keep], np.zeros(5, np.uint8), np.array(keep, np.uint32))
+    g3 = orc.build_incremental(ds3, g1, [], [], k3["to_delete"], M=3, M0=3, ef=100)
+    assert g3.entry_points.tolist() == k3["entry_points"] and g3.max_level == k3["max_level"]
+    assert _links_of(g3) == k3["links"]  # includes the reference's self-loops
+    # KAT-4: then delete item 1
+    k4 = kat["kat4"]
+    keep = [0, 2, 4, 5]
+    ds4 = orc.Dataset.from_f32(orc.EUCLIDEAN, v[keep], np.zeros(4, np.uint8), np.array(keep, np.uint32))
+    g4 = orc.build_incremental(ds4, g3, [], [], k4["to_delete"], M=3, M0=3, ef=100)
+    assert g4.entry_points.tolist() == k4["entry_points"] and g4.max_level == k4["max_level"]
+    assert _links_of(g4) == k4["links"]
