@@ -24,7 +24,7 @@ EXPORTED = [
     "hny_builder_next_batch", "hny_builder_search", "hny_builder_apply", "hny_builder_sync",
     "hny_builder_finish", "hny_builder_destroy", "hny_builder_set_profiling", "hny_batch_size", "hny_builder_distances",
     "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
-    "hny_encode_kv", "hny_last_error", "hny_version",
+    "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels",
 ]
 
 
@@ -111,6 +111,8 @@ def load_library():
     L.hny_builder_finish.restype = C.c_int
     L.hny_builder_finish.argtypes = [vp, C.POINTER(C.POINTER(GraphStruct))]
     L.hny_builder_destroy.argtypes = [vp]
+    L.hny_draw_levels.restype = C.c_int
+    L.hny_draw_levels.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, vp]
     L.hny_batch_size.restype = C.c_uint32
     L.hny_batch_size.argtypes = [C.c_double, C.c_uint32, C.c_uint64]
     L.hny_builder_distances.restype = C.c_int
@@ -141,6 +143,12 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def draw_levels(seed, M, n):
+    out = np.zeros(n, np.uint8)
+    _check(load_library().hny_draw_levels(seed, M, n, _p(out)))
+    return out
 
 
 def vector_bytes(metric, dim):

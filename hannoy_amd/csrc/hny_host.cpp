@@ -52,8 +52,7 @@ uint32_t pow2ceil(uint32_t x) {
   return p;
 }
 
-// ---- get_default_probas / get_random_level (hnsw.rs:94-119).  The reference draws from a caller
-// supplied rand::Rng; its ChaCha12 stream is not reproduced (levels can be injected instead). ----
+// ---- get_default_probas (hnsw.rs:94-110) ----
 std::vector<float> level_probas(uint32_t M) {
   std::vector<float> p;
   float level_factor = 1.0f / logf((float)M + 1.1920929e-07f);
@@ -64,15 +63,83 @@ std::vector<float> level_probas(uint32_t M) {
   }
   return p;
 }
-struct SplitMix64 {
-  uint64_t s;
-  uint64_t next() {
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// rand 0.8.5 StdRng = ChaCha12 block generator (key = 32-byte seed, 64-bit counter, stream 0)
+class StdRngChaCha12 {
+ public:
+  explicit StdRngChaCha12(uint64_t seed_u64) { // SeedableRng::seed_from_u64 (PCG32 expansion)
+    uint64_t st = seed_u64;
+    for (int c = 0; c < 8; c++) {
+      st = st * 6364136223846793005ull + 11634580027462260723ull;
+      uint32_t xs = (uint32_t)(((st >> 18) ^ st) >> 27), rot = (uint32_t)(st >> 59);
+      key_[c] = (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
   }
+  uint32_t next_u32() {
+    if (pos_ == 16) block();
+    return out_[pos_++];
+  }
+
+ private:
+  static uint32_t rl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+  void block() {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key_[0], key_[1], key_[2],
+                       key_[3], key_[4], key_[5], key_[6], key_[7], (uint32_t)ctr_,
+                       (uint32_t)(ctr_ >> 32), 0u, 0u};
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = in[i];
+    auto q = [&](int a, int b2, int c, int d) {
+      x[a] += x[b2]; x[d] = rl(x[d] ^ x[a], 16);
+      x[c] += x[d]; x[b2] = rl(x[b2] ^ x[c], 12);
+      x[a] += x[b2]; x[d] = rl(x[d] ^ x[a], 8);
+      x[c] += x[d]; x[b2] = rl(x[b2] ^ x[c], 7);
+    };
+    for (int r = 0; r < 12; r += 2) {
+      q(0, 4, 8, 12); q(1, 5, 9, 13); q(2, 6, 10, 14); q(3, 7, 11, 15);
+      q(0, 5, 10, 15); q(1, 6, 11, 12); q(2, 7, 8, 13); q(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) out_[i] = x[i] + in[i];
+    ctr_++;
+    pos_ = 0;
+  }
+  uint32_t key_[8], out_[16];
+  uint64_t ctr_ = 0;
+  int pos_ = 16;
 };
+
+// get_random_level (hnsw.rs:113-119): WeightedIndex<f32>::new(probas).sample(rng), one draw per
+// item in ascending id order (hnsw.rs:142-149).  Reproduces what the reference draws from
+// StdRng::seed_from_u64(seed) (the Python binding's rng, python.rs:261).
+void draw_levels(uint64_t seed, uint32_t M, uint32_t n, uint8_t *out) {
+  std::vector<float> p = level_probas(M);
+  std::vector<float> cum; // running totals, last weight excluded
+  float total = p[0];
+  for (size_t i = 1; i < p.size(); i++) {
+    cum.push_back(total);
+    total = total + p[i];
+  }
+  // UniformFloat<f32>::new(0, total): shrink the scale until the largest sample stays below total
+  uint32_t mb = (0xFFFFFFFFu >> 9) | 0x3F800000u;
+  float max_rand;
+  memcpy(&max_rand, &mb, 4);
+  max_rand -= 1.0f;
+  float scale = total;
+  while (scale * max_rand + 0.0f >= total) {
+    uint32_t sb;
+    memcpy(&sb, &scale, 4);
+    sb -= 1;
+    memcpy(&scale, &sb, 4);
+  }
+  StdRngChaCha12 rng(seed);
+  for (uint32_t s = 0; s < n; s++) {
+    uint32_t u = (rng.next_u32() >> 9) | 0x3F800000u;
+    float v;
+    memcpy(&v, &u, 4);
+    float x = (v - 1.0f) * scale + 0.0f;
+    size_t l = 0;
+    while (l < cum.size() && cum[l] <= x) l++; // partition_point(|w| w <= x)
+    out[s] = (uint8_t)l;
+  }
+}
 
 // ---- f32 dot in the reference's x86 order, for Distance::new_header (cosine.rs:36-38,58-60):
 // 32 fma partials + hsum tree (simple_avx.rs:8-13,69-110), 16 unfused partials for 16 <= n < 32
@@ -311,6 +378,12 @@ const char *hny_version(void) { return "hannoy_amd 0.1.0 (gfx950)"; }
 size_t hny_vector_bytes(int32_t metric, uint32_t dim) { return vec_bytes(metric, dim); }
 size_t hny_header_bytes(int32_t metric) { return hdr_bytes(metric); }
 
+int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out) {
+  if (!out || M == 0 || n >= (1ull << 31)) return fail(HNY_ERR_INVALID_ARG, "hny_draw_levels: bad argument");
+  draw_levels(seed, M, (uint32_t)n, out);
+  return HNY_OK;
+}
+
 uint32_t hny_batch_size(double frac, uint32_t bmax, uint64_t n_done) {
   if (bmax == 0) return 1;
   double v = std::floor(frac * (double)n_done);
@@ -433,16 +506,7 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   if (items->levels) {
     memcpy(b->level.data(), items->levels, n);
   } else {
-    std::vector<float> p = level_probas(o.M);
-    std::vector<double> cum(p.size());
-    double tot = 0;
-    for (size_t i = 0; i < p.size(); i++) cum[i] = (tot += p[i]);
-    SplitMix64 rng{o.seed};
-    for (uint32_t s = 0; s < n; s++) { // one draw per item in ascending id order
-      double u = (double)(rng.next() >> 11) * (1.0 / 9007199254740992.0) * tot;
-      size_t l = std::upper_bound(cum.begin(), cum.end(), u) - cum.begin();
-      b->level[s] = (uint8_t)std::min(l, p.size() - 1);
-    }
+    draw_levels(o.seed, o.M, n, b->level.data());
   }
   // ---- prepare_levels_and_entry_points, fresh DB (hnsw.rs:222-289) ----
   b->order.resize(n);

@@ -54,7 +54,8 @@ typedef struct {
   uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120) */
   uint32_t ef_construction;  /* default 100 (writer.rs:49) */
   float alpha;               /* default 1.0 (writer.rs:51) */
-  uint64_t seed;             /* level RNG seed when items.levels == NULL */
+  uint64_t seed;             /* levels when items.levels == NULL: drawn exactly as the reference
+                              * draws them from StdRng::seed_from_u64(seed) (python.rs:261) */
   int (*cancel)(void *);     /* polled between batches, at least every 10 000 items (lib.rs:140) */
   void *cancel_ctx;
   void (*progress)(void *, uint64_t done, uint64_t total); /* progress.rs:3-16 */
@@ -130,6 +131,9 @@ int hny_builder_sync(hny_builder *b);
 int hny_builder_set_profiling(hny_builder *b, int on);
 int hny_builder_finish(hny_builder *b, hny_graph **out);
 void hny_builder_destroy(hny_builder *b);
+/* get_random_level (hnsw.rs:113-119) for n items in ascending id order, as the reference draws
+ * them from StdRng::seed_from_u64(seed); what hny_build uses when items.levels == NULL */
+int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out);
 /* the schedule: batch size when n_done items are already inserted */
 uint32_t hny_batch_size(double batch_frac, uint32_t batch_max, uint64_t n_done);
 

@@ -713,6 +713,89 @@ uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap) {
   return level;
 }
 
+/* [3P] rand_chacha 0.3 ChaCha12Rng (rand 0.8.5 StdRng): 12 rounds, 64-bit block counter in words
+ * 12-13, stream id 0, output = successive blocks, words in order. */
+namespace {
+struct ChaCha12 {
+  uint32_t key[8];
+  uint64_t ctr = 0;
+  uint32_t buf[16];
+  int pos = 16;
+  static inline uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+  static inline void qr(uint32_t *s, int a, int b, int c, int d) {
+    s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
+    s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
+    s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
+    s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+  }
+  void refill() {
+    uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; i++) st[4 + i] = key[i];
+    st[12] = (uint32_t)ctr;
+    st[13] = (uint32_t)(ctr >> 32);
+    st[14] = st[15] = 0;
+    uint32_t w[16];
+    std::memcpy(w, st, sizeof w);
+    for (int r = 0; r < 6; r++) {
+      qr(w, 0, 4, 8, 12); qr(w, 1, 5, 9, 13); qr(w, 2, 6, 10, 14); qr(w, 3, 7, 11, 15);
+      qr(w, 0, 5, 10, 15); qr(w, 1, 6, 11, 12); qr(w, 2, 7, 8, 13); qr(w, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) buf[i] = w[i] + st[i];
+    ctr++;
+    pos = 0;
+  }
+  uint32_t next_u32() {
+    if (pos == 16) refill();
+    return buf[pos++];
+  }
+};
+} // namespace
+
+void orc_draw_levels(const uint8_t *seed32, uint64_t seed_u64, uint32_t M, uint64_t n, uint8_t *out) {
+  uint8_t seed[32];
+  if (seed32) {
+    std::memcpy(seed, seed32, 32);
+  } else { /* SeedableRng::seed_from_u64: PCG32 expansion */
+    uint64_t state = seed_u64;
+    for (int c = 0; c < 8; c++) {
+      state = state * 6364136223846793005ull + 11634580027462260723ull;
+      uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+      uint32_t rot = (uint32_t)(state >> 59);
+      uint32_t x = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+      std::memcpy(seed + 4 * c, &x, 4);
+    }
+  }
+  ChaCha12 rng;
+  std::memcpy(rng.key, seed, 32);
+  float probas[64];
+  uint32_t np = orc_level_probas(M, probas, 64);
+  /* WeightedIndex::new: running totals before each further weight; Uniform::new(0, total) */
+  std::vector<float> cum;
+  float total = probas[0];
+  for (uint32_t i = 1; i < np; i++) {
+    cum.push_back(total);
+    total = total + probas[i];
+  }
+  uint32_t mr = (0xFFFFFFFFu >> 9) | 0x3F800000u;
+  float max_rand;
+  std::memcpy(&max_rand, &mr, 4);
+  max_rand -= 1.0f;
+  float scale = total - 0.0f;
+  while (scale * max_rand + 0.0f >= total) {
+    uint32_t b = f32_bits(scale) - 1;
+    std::memcpy(&scale, &b, 4);
+  }
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t u = (rng.next_u32() >> 9) | 0x3F800000u;
+    float v12;
+    std::memcpy(&v12, &u, 4);
+    float x = (v12 - 1.0f) * scale + 0.0f;
+    size_t k = 0; /* cumulative_weights.partition_point(|w| w <= &chosen) */
+    while (k < cum.size() && cum[k] <= x) k++;
+    out[i] = (uint8_t)k;
+  }
+}
+
 int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
   if (!opts || !items || !out) return -1;
   if (opts->M == 0 || opts->M0 < opts->M) return -2;

@@ -10,10 +10,13 @@
  * this image (no cargo/rustc, no LMDB).  The restatement is pinned against the
  * reference's own golden expectations (tests/golden/kat_*.json, derived from
  * /root/reference/src/tests/writer.rs snapshots and the quantiser tests).
- * Third-party pieces with **parity unpinned** (no golden bytes in the
- * reference): rand 0.8.5 ChaCha12/WeightedIndex level sequence (levels are an
- * input here), roaring 0.10.9 serialisation (public RoaringFormatSpec
- * followed), heed/LMDB file format (not produced).
+ * Third-party pieces: rand 0.8.5 StdRng (ChaCha12) + WeightedIndex<f32> are
+ * restated (orc_draw_levels) and pinned by the level sequence the KAT-1 / KAT-5
+ * snapshots imply for StdRng::from_seed([42; 32]).  **Parity unpinned** (no
+ * golden bytes in the reference): roaring 0.10.9 serialisation (public
+ * RoaringFormatSpec followed), heed/LMDB file format (not produced), and the
+ * order Rust's sort_unstable_by leaves equal levels in for n > 20 (hnsw.rs:268;
+ * ascending id is used).
  *
  * All file:line citations are relative to /root/reference/.
  */
@@ -94,6 +97,11 @@ float orc_sqeuclid_x86_emulated(uint32_t dim, const float *a, const float *b);
 /* ---- level assignment (hnsw.rs:94-119) ---- */
 /* get_default_probas: returns count, writes up to cap probabilities */
 uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap);
+/* get_random_level (hnsw.rs:113-119) drawn n times from rand 0.8.5 StdRng (= ChaCha12Rng) through
+ * WeightedIndex<f32>.  [3P] restated from the published algorithms; pinned by the level sequence
+ * KAT-1 / KAT-5 imply for StdRng::from_seed([42; 32]) with M = 3.  seed32 != NULL: from_seed(seed32);
+ * else seed_from_u64(seed_u64) (python.rs:261).  skip = u32 words already consumed. */
+void orc_draw_levels(const uint8_t *seed32, uint64_t seed_u64, uint32_t M, uint64_t n, uint8_t *out);
 
 /* ---- build (hnsw.rs:122-216, fresh DB) ---- */
 int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out);

@@ -67,6 +67,7 @@ def lib():
             f.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_level_probas.restype = C.c_uint32
         L.orc_level_probas.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_draw_levels.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
         L.orc_build.restype = C.c_int
         L.orc_build.argtypes = [C.POINTER(Opts), C.POINTER(Items), C.POINTER(C.c_void_p)]
         L.orc_graph_free.argtypes = [C.c_void_p]
@@ -168,6 +169,14 @@ def level_probas(M):
     out = np.zeros(64, dtype=np.float32)
     n = lib().orc_level_probas(M, _p(out), 64)
     return out[:n].copy()
+
+
+def draw_levels(M, n, seed32=None, seed_u64=0):
+    """get_random_level x n from StdRng::from_seed(seed32) or ::seed_from_u64(seed_u64)."""
+    out = np.zeros(n, np.uint8)
+    sd = None if seed32 is None else np.ascontiguousarray(seed32, np.uint8)
+    lib().orc_draw_levels(None if sd is None else _p(sd), seed_u64, M, n, _p(out))
+    return out
 
 
 def batch_size(frac, bmax, n_done):

@@ -184,3 +184,9 @@ def test_roaring_serialisation_shapes(hny, orc):
     meta = recs[0][1]
     rsz = int.from_bytes(meta[14:18], "big")
     assert meta[18:18 + rsz] == orc.roaring_serialize(big)
+
+
+def test_level_draws_match_oracle_rng(hny, orc):
+    """hny_draw_levels == the oracle's restated StdRng::seed_from_u64 + WeightedIndex draws."""
+    for seed, M in ((42, 16), (0, 3), (2 ** 63 + 5, 32), (7, 4)):
+        assert np.array_equal(hny.draw_levels(seed, M, 50000), orc.draw_levels(M, 50000, seed_u64=seed))
