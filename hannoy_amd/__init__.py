@@ -3,7 +3,7 @@
 The compute path is the HIP extension hannoy_amd/libhannoy_amd.so (C ABI: include/hannoy_amd.h).
 """
 from ._capi import (BQ_COSINE, BQ_EUCLIDEAN, BQ_MANHATTAN, COSINE, EUCLIDEAN, HAMMING, MANHATTAN,  # noqa: F401
-                    METRIC_NAMES, BuildCancelled, Builder, Graph, HannoyError, ItemSet, build, draw_levels,
+                    METRIC_NAMES, BuildCancelled, Builder, Graph, HannoyError, ItemSet, build, build_incremental, draw_levels,
                     encode_vectors, header_bytes, load_library, make_opts, vector_bytes)
 
 __all__ = ["Builder", "Graph", "ItemSet", "build", "encode_vectors", "load_library", "HannoyError",

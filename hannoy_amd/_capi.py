@@ -24,7 +24,7 @@ EXPORTED = [
     "hny_builder_next_batch", "hny_builder_search", "hny_builder_apply", "hny_builder_sync",
     "hny_builder_finish", "hny_builder_destroy", "hny_builder_set_profiling", "hny_batch_size", "hny_builder_distances",
     "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
-    "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels",
+    "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels", "hny_build_incremental",
 ]
 
 
@@ -73,6 +73,12 @@ class GraphStruct(C.Structure):
                 ("n_walk_launches", C.c_uint64)]
 
 
+class PrevGraph(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("rec_item", C.c_void_p), ("rec_layer", C.c_void_p),
+                ("rec_offset", C.c_void_p), ("neighbours", C.c_void_p), ("entry_points", C.c_void_p),
+                ("n_entry_points", C.c_uint32), ("max_level", C.c_uint32)]
+
+
 class Batch(C.Structure):
     _fields_ = [("first", C.c_uint64), ("count", C.c_uint32), ("level", C.c_uint32),
                 ("n_layers", C.c_uint32), ("sel_stride_u64", C.c_uint32)]
@@ -95,6 +101,10 @@ def load_library():
     L.hny_build.restype = C.c_int
     L.hny_build.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(C.POINTER(GraphStruct))]
     L.hny_graph_free.argtypes = [C.POINTER(GraphStruct)]
+    L.hny_build_incremental.restype = C.c_int
+    L.hny_build_incremental.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), vp, C.c_uint64, vp,
+                                        C.c_uint64, C.POINTER(PrevGraph),
+                                        C.POINTER(C.POINTER(GraphStruct))]
     L.hny_builder_create.restype = C.c_int
     L.hny_builder_create.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(vp)]
     for name in ("hny_builder_reset", "hny_builder_sync"):
@@ -264,6 +274,26 @@ def build(items, **kw):
     it = items.struct()
     gp = C.POINTER(GraphStruct)()
     _check(load_library().hny_build(C.byref(o), C.byref(it), C.byref(gp)))
+    return Graph(gp, o, items)
+
+
+def build_incremental(items, prev, to_insert, to_delete, **kw):
+    """hny_build_incremental: `items` = every item present after the update (levels, if any: one per
+    to_insert id); `prev` = graph of the previous build (anything with rec_item/rec_layer/offsets/
+    nbrs/entry_points/max_level)."""
+    o = make_opts(items.metric, items.dim, **kw)
+    it = items.struct()
+    ins = np.ascontiguousarray(to_insert, np.uint32)
+    dl = np.ascontiguousarray(to_delete, np.uint32)
+    keep = [np.ascontiguousarray(prev.rec_item, np.uint32), np.ascontiguousarray(prev.rec_layer, np.uint8),
+            np.ascontiguousarray(prev.offsets, np.uint64),
+            np.ascontiguousarray(prev.nbrs if len(prev.nbrs) else np.zeros(1), np.uint32),
+            np.ascontiguousarray(prev.entry_points, np.uint32)]
+    pg = PrevGraph(len(keep[0]), _p(keep[0]).value, _p(keep[1]).value, _p(keep[2]).value,
+                   _p(keep[3]).value, _p(keep[4]).value, len(keep[4]), int(prev.max_level))
+    gp = C.POINTER(GraphStruct)()
+    _check(load_library().hny_build_incremental(C.byref(o), C.byref(it), _p(ins), len(ins), _p(dl),
+                                                len(dl), C.byref(pg), C.byref(gp)))
     return Graph(gp, o, items)
 
 

@@ -215,6 +215,14 @@ struct hny_builder {
   std::vector<uint32_t> ids;
   std::vector<uint8_t> level;
   std::vector<uint32_t> order;        // insertion order (slots), level desc, id asc inside a level
+  std::vector<uint8_t> order_level;   // level of each insertion (an item can be re-inserted)
+  std::vector<int8_t> ins_level;      // highest level a slot is inserted at in this build, -1 = none
+  std::vector<uint8_t> old_mask;      // incremental: bit l = an old Links record (slot, l) exists
+  std::vector<uint8_t> deleted;       // incremental: slot is in to_delete
+  std::vector<u64> old_recs;          // incremental: surviving old records, layer << 31 | slot
+  bool incremental = false;
+  uint64_t n_done0 = 0;
+  uint32_t up_layers = 1;
   std::vector<uint32_t> entry_points; // slots ascending
   std::vector<int32_t> upper_idx;
   uint32_t max_level = 0, n_upper = 0;
@@ -234,7 +242,9 @@ struct hny_builder {
   DevBuf<float> d_norms, d_l0_dist, d_up_dist;
   DevBuf<int> d_upper_idx;
   DevBuf<u32> d_l0_ids, d_l0_cnt, d_up_ids, d_up_cnt, d_order, d_eps, d_bits, d_vlog, d_cand_n,
-      d_seg_start, d_nseg, d_deferred, d_fin_cnt0, d_fin_cntu;
+      d_seg_start, d_nseg, d_deferred, d_fin_cnt0, d_fin_cntu, d_d0_ids, d_du_ids;
+  DevBuf<unsigned char> d_has_vec, d_deleted;
+  DevBuf<u64> d_old_recs;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
   DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
@@ -353,7 +363,7 @@ int reset_graph(hny_builder *b) {
   HIP_TRY(hipMemsetAsync(b->d_stats.p, 0, ST_COUNT * 8, st));
   HIP_TRY(hipMemsetAsync(b->d_bits.p, 0, b->d_bits.n * 4, st));
   b->pos = 0;
-  b->n_done = 0;
+  b->n_done = b->n_done0;
   b->n_batches = 0;
   b->in_batch = false;
   b->finalized = false;
@@ -364,7 +374,7 @@ int reset_graph(hny_builder *b) {
 
 size_t group_end(const hny_builder *b, size_t pos) {
   size_t e = pos;
-  while (e < b->n && b->level[b->order[e]] == b->level[b->order[pos]]) e++;
+  while (e < b->order.size() && b->order_level[e] == b->order_level[pos]) e++;
   return e;
 }
 
@@ -454,7 +464,17 @@ void hny_builder_destroy(hny_builder *b) {
   delete b;
 }
 
-int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out) {
+// incremental-build inputs (hny_build_incremental); null for a fresh index
+struct IncrementalSpec {
+  const uint32_t *to_insert;
+  uint64_t n_insert;
+  const uint32_t *to_delete;
+  uint64_t n_delete;
+  const hny_prev_graph *prev;
+};
+
+static int create_impl(const hny_build_opts *opts, const hny_items *items, const IncrementalSpec *inc,
+                       hny_builder **out) {
   if (!opts || !items || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   const hny_build_opts &o = *opts;
@@ -479,10 +499,9 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
 
   auto b = std::unique_ptr<hny_builder, void (*)(hny_builder *)>(new hny_builder(), hny_builder_destroy);
   b->o = o;
-  b->n = (uint32_t)items->n;
-  const uint32_t n = b->n;
   b->frac = o.batch_frac > 0.0 ? o.batch_frac : 0.25;
   b->bmax = o.batch_max ? o.batch_max : 32768u;
+  b->incremental = inc != nullptr;
   uint32_t n16;
   int rc = pick_shape(o.metric, o.dim, b->shape, n16);
   if (rc) return rc;
@@ -500,25 +519,148 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   hipStream_t st = b->stream;
   double t0 = now_s();
 
-  // ---- levels (hnsw.rs:141-149) ----
-  b->ids.assign(items->ids, items->ids + n);
-  b->level.resize(n);
-  if (items->levels) {
-    memcpy(b->level.data(), items->levels, n);
-  } else {
-    draw_levels(o.seed, o.M, n, b->level.data());
+  // ---- slot universe: fresh = the items; incremental = items U deleted U everything the old graph
+  // mentions (ids ascending => slot order == id order) ----
+  std::vector<uint32_t> &U = b->ids;
+  U.assign(items->ids, items->ids + items->n);
+  if (inc) {
+    const hny_prev_graph *pg = inc->prev;
+    if (!pg || (inc->n_insert && !inc->to_insert) || (inc->n_delete && !inc->to_delete))
+      return fail(HNY_ERR_INVALID_ARG, "incremental: null argument");
+    U.insert(U.end(), inc->to_delete, inc->to_delete + inc->n_delete);
+    U.insert(U.end(), pg->rec_item, pg->rec_item + pg->n_records);
+    if (pg->n_records) U.insert(U.end(), pg->neighbours, pg->neighbours + pg->rec_offset[pg->n_records]);
+    U.insert(U.end(), pg->entry_points, pg->entry_points + pg->n_entry_points);
+    std::sort(U.begin(), U.end());
+    U.erase(std::unique(U.begin(), U.end()), U.end());
+    if (U.size() >= (1ull << 31)) return fail(HNY_ERR_UNSUPPORTED, "n >= 2^31");
   }
-  // ---- prepare_levels_and_entry_points, fresh DB (hnsw.rs:222-289) ----
-  b->order.resize(n);
-  for (uint32_t s = 0; s < n; s++) b->order[s] = s;
-  std::stable_sort(b->order.begin(), b->order.end(),
-                   [&](uint32_t x, uint32_t y) { return b->level[x] > b->level[y]; });
-  b->max_level = n ? b->level[b->order[0]] : 0;
+  b->n = (uint32_t)U.size();
+  const uint32_t n = b->n;
+  auto slot_of = [&](uint32_t id) { return (uint32_t)(std::lower_bound(U.begin(), U.end(), id) - U.begin()); };
+
+  std::vector<uint8_t> has_vec(n, inc ? 0 : 1);
+  std::vector<uint32_t> item_slot(items->n);
+  for (uint64_t i = 0; i < items->n; i++) {
+    item_slot[i] = inc ? slot_of(items->ids[i]) : (uint32_t)i;
+    has_vec[item_slot[i]] = 1;
+  }
+  b->ins_level.assign(n, -1);
+  b->old_mask.assign(n, 0);
+  b->deleted.assign(n, 0);
+  std::vector<std::pair<uint32_t, uint8_t>> levels; // (slot, level) in the reference's order
+
+  if (!inc) {
+    // ---- levels (hnsw.rs:141-149) + prepare_levels_and_entry_points, fresh DB (:222-289) ----
+    std::vector<uint8_t> lv(n);
+    if (items->levels)
+      memcpy(lv.data(), items->levels, n);
+    else
+      draw_levels(o.seed, o.M, n, lv.data());
+    for (uint32_t s = 0; s < n; s++) levels.push_back({s, lv[s]});
+    std::stable_sort(levels.begin(), levels.end(),
+                     [](const std::pair<uint32_t, uint8_t> &x, const std::pair<uint32_t, uint8_t> &y) {
+                       return x.second > y.second;
+                     });
+    b->max_level = n ? levels[0].second : 0;
+    for (uint32_t s = 0; s < n; s++)
+      if (lv[s] == b->max_level) b->entry_points.push_back(s);
+  } else {
+    // ---- incremental: writer.rs:539-554 set algebra is the caller's; here hnsw.rs:141-149 and the
+    // deletion branch of prepare_levels_and_entry_points (:236-289) ----
+    const hny_prev_graph *pg = inc->prev;
+    for (uint64_t i = 0; i < inc->n_delete; i++) b->deleted[slot_of(inc->to_delete[i])] = 1;
+    for (uint64_t r = 0; r < pg->n_records; r++) {
+      if (pg->rec_layer[r] > 7) return fail(HNY_ERR_INVALID_ARG, "old record on layer > 7");
+      b->old_mask[slot_of(pg->rec_item[r])] |= (uint8_t)(1u << pg->rec_layer[r]);
+    }
+    std::vector<uint8_t> lv(inc->n_insert);
+    if (items->levels)
+      memcpy(lv.data(), items->levels, inc->n_insert); // one per to_insert id, ascending
+    else
+      draw_levels(o.seed, o.M, (uint32_t)inc->n_insert, lv.data());
+    uint32_t cur_max = 0;
+    for (uint64_t i = 0; i < inc->n_insert; i++) {
+      if (i && inc->to_insert[i] <= inc->to_insert[i - 1]) return fail(HNY_ERR_INVALID_ARG, "to_insert not ascending");
+      uint32_t s = slot_of(inc->to_insert[i]);
+      if (s >= n || U[s] != inc->to_insert[i] || !has_vec[s])
+        return fail(HNY_ERR_MISSING_KEY, "to_insert id %u has no item", inc->to_insert[i]); // Error::MissingKey
+      levels.push_back({s, lv[i]});
+      cur_max = std::max<uint32_t>(cur_max, lv[i]);
+    }
+    uint32_t max_level = pg->max_level;
+    std::vector<uint8_t> in_new(n, 0), in_old(n, 0);
+    uint32_t n_old = 0, n_new = 0;
+    std::vector<uint32_t> del_eps;
+    for (uint32_t i = 0; i < pg->n_entry_points; i++) {
+      uint32_t s = slot_of(pg->entry_points[i]);
+      if (!in_old[s]) { in_old[s] = 1; n_old++; }
+      if (b->deleted[s]) del_eps.push_back(s);
+      else if (!in_new[s]) { in_new[s] = 1; n_new++; }
+    }
+    uint32_t l = max_level;
+    for (size_t k = 0; k < del_eps.size(); k++) { // :243-257 replace deleted entry points
+      for (;;) {
+        if (l <= 7)
+          for (uint32_t s = 0; s < n; s++) // iter_layer_links(l): ascending item
+            if (((b->old_mask[s] >> l) & 1) && !b->deleted[s] && !in_new[s]) {
+              in_new[s] = 1;
+              n_new++;
+              break;
+            }
+        if (l == 0) break;
+        l -= 1;
+      }
+    }
+    if (!del_eps.empty() && n_new != n_old) max_level = 0; // :261-263
+    for (uint32_t s = 0; s < n; s++)
+      if (in_new[s]) levels.push_back({s, (uint8_t)max_level}); // :267
+    std::stable_sort(levels.begin(), levels.end(),
+                     [](const std::pair<uint32_t, uint8_t> &x, const std::pair<uint32_t, uint8_t> &y) {
+                       return x.second > y.second;
+                     }); // :268
+    if (cur_max > max_level) { // :272-276
+      std::fill(in_new.begin(), in_new.end(), 0);
+      max_level = cur_max;
+    }
+    for (auto &pr : levels) { // :278-285
+      if (pr.second != max_level) break;
+      in_new[pr.first] = 1;
+    }
+    b->max_level = max_level;
+    for (uint32_t s = 0; s < n; s++)
+      if (in_new[s]) {
+        b->entry_points.push_back(s);
+        if (!has_vec[s]) return fail(HNY_ERR_MISSING_KEY, "entry point %u has no item", U[s]);
+      }
+    for (uint32_t s = 0; s < n; s++) // schedule: surviving old layer-0 records count as inserted
+      if ((b->old_mask[s] & 1) && !b->deleted[s]) b->n_done0++;
+    for (uint32_t s = 0; s < n; s++)
+      for (uint32_t ll = 0; ll < 8; ll++)
+        if (((b->old_mask[s] >> ll) & 1) && !b->deleted[s]) b->old_recs.push_back(((u64)ll << 31) | s);
+  }
   if (b->max_level > 7) return fail(HNY_ERR_INVALID_ARG, "level > 7");
+  for (auto &pr : levels) {
+    b->order.push_back(pr.first);
+    b->order_level.push_back(pr.second);
+    b->ins_level[pr.first] = std::max<int8_t>(b->ins_level[pr.first], (int8_t)pr.second);
+  }
+  for (uint32_t s : b->entry_points) // pre-registered in every layer (:278-285)
+    b->ins_level[s] = std::max<int8_t>(b->ins_level[s], (int8_t)b->max_level);
+  // storage level of a slot = highest layer it can own a list on
+  b->level.assign(n, 0);
   b->upper_idx.assign(n, -1);
+  b->up_layers = std::max<uint32_t>(b->max_level, 1);
   for (uint32_t s = 0; s < n; s++) {
-    if (b->level[s] == b->max_level) b->entry_points.push_back(s);
-    if (b->level[s] >= 1) b->upper_idx[s] = (int32_t)b->n_upper++;
+    int top = b->ins_level[s] > 0 ? b->ins_level[s] : 0;
+    for (int ll = 7; ll > top; ll--)
+      if ((b->old_mask[s] >> ll) & 1) {
+        top = ll;
+        break;
+      }
+    b->level[s] = (uint8_t)top;
+    if (top >= 1) b->upper_idx[s] = (int32_t)b->n_upper++;
+    b->up_layers = std::max<uint32_t>(b->up_layers, (uint32_t)top);
   }
   if (b->entry_points.size() > HNY_MAX_EPS)
     return fail(HNY_ERR_UNSUPPORTED, "%zu entry points > %d", b->entry_points.size(), HNY_MAX_EPS);
@@ -529,9 +671,9 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   b->max_batch = 1;
   b->max_ops = 2;
   b->sel_words = 2;
-  for (size_t pos = 0; pos < n;) {
+  for (size_t pos = 0; pos < b->order.size();) {
     size_t e = group_end(b.get(), pos);
-    uint32_t L = b->level[b->order[pos]];
+    uint32_t L = b->order_level[pos];
     uint64_t bs = std::min<uint64_t>(b->bmax, e - pos);
     uint64_t cs = cap_of(b.get(), L);
     b->max_batch = std::max<uint32_t>(b->max_batch, (uint32_t)bs);
@@ -545,7 +687,7 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
   {
-    // LDS staging budget of the workgroup prune: <= 48 KiB of rows, whole load groups
+    // LDS staging budget of the workgroup prune, whole load groups
     int rpg = 64 / b->shape.lpr;
     int sl = (int)((u32)std::max(0, env_int("HNY_STAGE_BYTES", 24576)) / (n16 * 16u));
     if (sl > HNY_MAX_CAP) sl = HNY_MAX_CAP;
@@ -564,9 +706,12 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   g.M = o.M;
   g.M0 = o.M0;
   g.max_level = b->max_level;
+  g.up_layers = b->up_layers;
   g.n_upper = b->n_upper;
   g.alpha = o.alpha;
+  g.incremental = inc ? 1 : 0;
   const size_t nn = std::max<uint32_t>(n, 1);
+  const size_t no = std::max<size_t>(b->order.size(), 1);
   HIP_TRY(b->d_rows.alloc(nn * g.row_stride));
   HIP_TRY(b->d_level.alloc(nn));
   HIP_TRY(b->d_upper_idx.alloc(nn));
@@ -575,11 +720,11 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   HIP_TRY(b->d_l0_ids.alloc(nn * o.M0));
   HIP_TRY(b->d_l0_dist.alloc(nn * o.M0));
   HIP_TRY(b->d_l0_cnt.alloc(nn));
-  const size_t nup = (size_t)b->n_upper * std::max<uint32_t>(b->max_level, 1);
+  const size_t nup = (size_t)b->n_upper * b->up_layers;
   HIP_TRY(b->d_up_ids.alloc(nup * o.M));
   HIP_TRY(b->d_up_dist.alloc(nup * o.M));
   HIP_TRY(b->d_up_cnt.alloc(nup));
-  HIP_TRY(b->d_order.alloc(nn));
+  HIP_TRY(b->d_order.alloc(no));
   HIP_TRY(b->d_fin_cnt0.alloc(nn));
   HIP_TRY(b->d_fin_cntu.alloc(std::max<size_t>(nup, 1)));
   HIP_TRY(hipHostMalloc((void **)&b->h_l0, nn * o.M0 * 4));
@@ -621,20 +766,70 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
 
   // ---- upload (the "export to HBM" that replaces FrozenReader, parallel.rs:11-45) ----
   if (n) {
-    rc = upload_rows(items->vectors, items->stride, vb, n, g.row_stride, b->d_rows.p, st);
-    if (rc) return rc;
+    if (!inc) {
+      rc = upload_rows(items->vectors, items->stride, vb, n, g.row_stride, b->d_rows.p, st);
+      if (rc) return rc;
+    } else {
+      HIP_TRY(hipMemsetAsync(b->d_rows.p, 0, (size_t)n * g.row_stride, st));
+      const size_t chunk = std::max<size_t>(1, (64u << 20) / g.row_stride);
+      std::vector<unsigned char> stage(chunk * g.row_stride);
+      uint64_t i = 0;
+      for (uint32_t s0 = 0; s0 < n; s0 += (uint32_t)chunk) { // items are a subset of the universe
+        uint32_t cnt = (uint32_t)std::min<size_t>(chunk, n - s0);
+        std::fill(stage.begin(), stage.begin() + (size_t)cnt * g.row_stride, 0);
+        for (; i < items->n && item_slot[i] < s0 + cnt; i++)
+          memcpy(&stage[(size_t)(item_slot[i] - s0) * g.row_stride],
+                 (const unsigned char *)items->vectors + i * items->stride, vb);
+        HIP_TRY(hipMemcpyAsync(b->d_rows.p + (size_t)s0 * g.row_stride, stage.data(),
+                               (size_t)cnt * g.row_stride, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+      }
+    }
     HIP_TRY(hipMemcpyAsync(b->d_level.p, b->level.data(), n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b->d_upper_idx.p, b->upper_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->d_order.p, b->order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (!b->order.empty())
+      HIP_TRY(hipMemcpyAsync(b->d_order.p, b->order.data(), b->order.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b->d_eps.p, b->entry_points.data(), b->entry_points.size() * 4,
                            hipMemcpyHostToDevice, st));
     std::vector<float> norms;
     if (has_norm) {
-      norms.resize(n);
-      for (uint32_t s = 0; s < n; s++) memcpy(&norms[s], (const unsigned char *)items->headers + (size_t)s * hb, 4);
+      norms.assign(n, 0.f);
+      for (uint64_t i = 0; i < items->n; i++)
+        memcpy(&norms[item_slot[i]], (const unsigned char *)items->headers + (size_t)i * hb, 4);
       HIP_TRY(hipMemcpyAsync(b->d_norms.p, norms.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (inc && n) {
+    // the previous graph, as Links records: ascending ids, HNY_SENT padded
+    const hny_prev_graph *pg = inc->prev;
+    std::vector<u32> d0((size_t)n * o.M0, HNY_SENT), du(std::max<size_t>(nup * o.M, 1), HNY_SENT);
+    for (uint64_t r = 0; r < pg->n_records; r++) {
+      uint32_t s = slot_of(pg->rec_item[r]), ll = pg->rec_layer[r];
+      uint64_t c = pg->rec_offset[r + 1] - pg->rec_offset[r];
+      uint32_t cap = ll == 0 ? o.M0 : o.M;
+      if (c > cap) return fail(HNY_ERR_UNSUPPORTED, "old record (%u, %u) has %llu > %u links", U[s], ll,
+                               (unsigned long long)c, cap);
+      u32 *dst = ll == 0 ? &d0[(size_t)s * o.M0]
+                         : &du[((size_t)b->upper_idx[s] * b->up_layers + (ll - 1)) * o.M];
+      for (uint64_t k = 0; k < c; k++) dst[k] = slot_of(pg->neighbours[pg->rec_offset[r] + k]);
+    }
+    HIP_TRY(b->d_d0_ids.alloc(d0.size()));
+    HIP_TRY(b->d_du_ids.alloc(du.size()));
+    HIP_TRY(b->d_has_vec.alloc(n));
+    HIP_TRY(b->d_deleted.alloc(n));
+    HIP_TRY(b->d_old_recs.alloc(std::max<size_t>(b->old_recs.size(), 1)));
+    HIP_TRY(hipMemcpyAsync(b->d_d0_ids.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_du_ids.p, du.data(), du.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_has_vec.p, has_vec.data(), n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_deleted.p, b->deleted.data(), n, hipMemcpyHostToDevice, st));
+    if (!b->old_recs.empty())
+      HIP_TRY(hipMemcpyAsync(b->d_old_recs.p, b->old_recs.data(), b->old_recs.size() * 8,
+                             hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    g.d0_ids = b->d_d0_ids.p;
+    g.du_ids = b->d_du_ids.p;
+    g.has_vec = b->d_has_vec.p;
   }
   rc = reset_graph(b.get());
   if (rc) return rc;
@@ -643,6 +838,10 @@ int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_b
   b->t_build0 = now_s();
   *out = b.release();
   return HNY_OK;
+}
+
+int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out) {
+  return create_impl(opts, items, nullptr, out);
 }
 
 int hny_builder_reset(hny_builder *b) {
@@ -654,11 +853,11 @@ int hny_builder_reset(hny_builder *b) {
 int hny_builder_next_batch(hny_builder *b, hny_batch *out) {
   if (!b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
   if (b->in_batch) return fail(HNY_ERR_INVALID_ARG, "previous batch not applied");
-  if (b->finalized && b->pos < b->n) return fail(HNY_ERR_INVALID_ARG, "graph already finalised");
+  if (b->finalized && b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "graph already finalised");
   memset(out, 0, sizeof *out);
-  if (b->pos >= b->n) return HNY_OK;
+  if (b->pos >= b->order.size()) return HNY_OK;
   size_t gend = group_end(b, b->pos);
-  uint32_t L = b->level[b->order[b->pos]];
+  uint32_t L = b->order_level[b->pos];
   uint64_t bs = hny_batch_size(b->frac, b->bmax, b->n_done);
   bs = std::min<uint64_t>(bs, gend - b->pos);
   out->first = b->pos;
@@ -802,7 +1001,7 @@ void hny_graph_free(hny_graph *g) {
 int hny_builder_finish(hny_builder *b, hny_graph **out) {
   if (!b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
-  if (b->pos < b->n || b->in_batch) return fail(HNY_ERR_INVALID_ARG, "build not finished");
+  if (b->pos < b->order.size() || b->in_batch) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->t_build = now_s() - b->t_build0;
@@ -810,11 +1009,12 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   const uint32_t n = b->n, M = b->o.M, M0 = b->o.M0, ml = b->max_level;
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
-    return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
-                stats[ST_ERR_ITER]);
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER] || stats[ST_ERR_GAPS_OVERFLOW])
+    return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu gaps=%llu", stats[ST_ERR_RES_OVERFLOW],
+                stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW]);
   // finalise every list on the device (sort + dedup), then copy through pinned staging
-  const size_t nup = (size_t)b->n_upper * std::max(ml, 1u);
+  const uint32_t upl = b->up_layers;
+  const size_t nup = (size_t)b->n_upper * upl;
   if (!b->finalized) {
     HIP_TRY(hnyk_finalize_lists(b->d_l0_ids.p, b->d_fin_cnt0.p, n, M0, b->stream));
     HIP_TRY(hnyk_finalize_lists(b->d_up_ids.p, b->d_fin_cntu.p, (u32)nup, M, b->stream));
@@ -832,36 +1032,50 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   const u32 *l0 = b->h_l0, *up = b->h_up;
 
   // every inserted item owns a (possibly empty) record on layers 0..=level (add_in_layers_below,
-  // hnsw.rs:419-424)
+  // hnsw.rs:419-424); after an incremental build every surviving old record is rewritten too
+  // (fill_gaps_from_deleted puts it in memory, :398/:410) and deleted items own nothing
+  // (delete_links_from_db, writer.rs:692-718)
+  auto rec_mask = [&](uint32_t s) -> uint32_t {
+    if (b->deleted[s]) return 0u;
+    uint32_t m = b->old_mask[s];
+    if (b->ins_level[s] >= 0) m |= (2u << b->ins_level[s]) - 1u;
+    return m;
+  };
   std::vector<uint64_t> rec_first(n + 1, 0);
-  for (uint32_t s = 0; s < n; s++) rec_first[s + 1] = rec_first[s] + b->level[s] + 1;
+  for (uint32_t s = 0; s < n; s++) rec_first[s + 1] = rec_first[s] + (uint32_t)__builtin_popcount(rec_mask(s));
   const uint64_t nrec = rec_first[n];
   hny_graph *g = (hny_graph *)calloc(1, sizeof(hny_graph));
   uint32_t *rec_item = (uint32_t *)malloc(std::max<uint64_t>(nrec, 1) * 4);
   uint8_t *rec_layer = (uint8_t *)malloc(std::max<uint64_t>(nrec, 1));
   uint64_t *rec_off = (uint64_t *)malloc((nrec + 1) * 8);
   rec_off[0] = 0;
-  for (uint32_t s = 0; s < n; s++) // offsets: sequential prefix over the device-computed counts
-    for (uint32_t l = 0; l <= b->level[s]; l++) {
-      uint64_t r = rec_first[s] + l;
-      uint32_t c = l == 0 ? b->h_cnt0[s] : b->h_cntu[(size_t)b->upper_idx[s] * ml + (l - 1)];
+  for (uint32_t s = 0; s < n; s++) { // offsets: sequential prefix over the device-computed counts
+    uint64_t r = rec_first[s];
+    for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++) {
+      if (!(m & 1)) continue;
+      uint32_t c = l == 0 ? b->h_cnt0[s] : b->h_cntu[(size_t)b->upper_idx[s] * upl + (l - 1)];
       rec_off[r + 1] = rec_off[r] + c;
+      r++;
     }
+  }
   uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (n < 10000) nt = 1;
   auto work = [&](uint32_t lo, uint32_t hi) {
-    for (uint32_t s = lo; s < hi; s++)
-      for (uint32_t l = 0; l <= b->level[s]; l++) {
-        uint64_t r = rec_first[s] + l;
+    for (uint32_t s = lo; s < hi; s++) {
+      uint64_t r = rec_first[s];
+      for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++) {
+        if (!(m & 1)) continue;
         rec_item[r] = b->ids[s];
         rec_layer[r] = (uint8_t)l;
         const u32 *src = l == 0 ? &l0[(size_t)s * M0]
-                                : &up[((size_t)b->upper_idx[s] * ml + (l - 1)) * M];
+                                : &up[((size_t)b->upper_idx[s] * upl + (l - 1)) * M];
         uint32_t c = (uint32_t)(rec_off[r + 1] - rec_off[r]);
         uint32_t *dst = nbrs + rec_off[r];
         for (uint32_t k = 0; k < c; k++) dst[k] = b->ids[src[k]]; // slot -> item id (order kept)
+        r++;
       }
+    }
   };
   {
     std::vector<std::thread> th;
@@ -934,8 +1148,53 @@ int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **ou
     rc = hny_builder_apply(b, nullptr);
     if (rc) break;
     since_probe += bt.count;
-    if (opts->progress) opts->progress(opts->progress_ctx, b->n_done, b->n);
+    if (opts->progress) opts->progress(opts->progress_ctx, b->pos, b->order.size());
   }
+  if (!rc) rc = hny_builder_finish(b, out);
+  hny_builder_destroy(b);
+  return rc;
+}
+
+// fill_gaps_from_deleted (hnsw.rs:187, 334-415): merge old and new links of every surviving old
+// record and bridge the holes deleted items leave
+static int run_fill_gaps(hny_builder *b) {
+  if (!b->incremental || b->old_recs.empty()) return HNY_OK;
+  prof_begin(b, EV_APPLY);
+  HIP_TRY(hnyk_fill_gaps(b->g, b->d_old_recs.p, (u32)b->old_recs.size(), b->d_deleted.p, b->shape,
+                         b->stream));
+  prof_end(b);
+  return HNY_OK;
+}
+
+int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
+                          uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
+                          const hny_prev_graph *prev, hny_graph **out) {
+  if (!out) return fail(HNY_ERR_INVALID_ARG, "null out");
+  *out = nullptr;
+  IncrementalSpec inc{to_insert, n_insert, to_delete, n_delete, prev};
+  hny_builder *b = nullptr;
+  int rc = create_impl(opts, items, &inc, &b);
+  if (rc) return rc;
+  uint64_t since_probe = 0;
+  for (;;) {
+    if (opts->cancel && (since_probe == 0 || since_probe >= 10000)) {
+      since_probe = 0;
+      if (opts->cancel(opts->cancel_ctx)) {
+        hny_builder_destroy(b);
+        return fail(HNY_ERR_CANCELLED, "build cancelled");
+      }
+    }
+    hny_batch bt;
+    rc = hny_builder_next_batch(b, &bt);
+    if (rc || bt.count == 0) break;
+    rc = hny_builder_search(b, 0, bt.count, nullptr);
+    if (rc) break;
+    rc = hny_builder_apply(b, nullptr);
+    if (rc) break;
+    since_probe += bt.count;
+    if (opts->progress) opts->progress(opts->progress_ctx, b->pos, b->order.size());
+  }
+  if (!rc) rc = run_fill_gaps(b);
   if (!rc) rc = hny_builder_finish(b, out);
   hny_builder_destroy(b);
   return rc;
@@ -966,7 +1225,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
                            float *out_dists, uint32_t *out_counts) {
   if (!b || !qvectors || !qheaders || !out_ids || !out_dists || !out_counts || k == 0)
     return fail(HNY_ERR_INVALID_ARG, "bad argument");
-  if (b->pos < b->n) return fail(HNY_ERR_INVALID_ARG, "build not finished");
+  if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   const uint32_t ef = std::max(ef_search, k); // reader.rs:746
   if (ef + 1 > b->rcap && ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
   HIP_TRY(hipSetDevice(b->device));
@@ -977,7 +1236,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
   if (!b->finalized) { // Reader::visit iterates Links bitmaps: ascending, deduplicated
     HIP_TRY(hnyk_finalize_lists(b->d_l0_ids.p, b->d_fin_cnt0.p, b->n, b->o.M0, b->stream));
     HIP_TRY(hnyk_finalize_lists(b->d_up_ids.p, b->d_fin_cntu.p,
-                                (u32)((size_t)b->n_upper * std::max(b->max_level, 1u)), b->o.M, b->stream));
+                                (u32)((size_t)b->n_upper * b->up_layers), b->o.M, b->stream));
     b->finalized = true;
   }
   uint32_t rcap = 64;

@@ -28,6 +28,7 @@ enum {
   ST_LOG_OVERFLOW = 5,
   ST_ERR_RES_OVERFLOW = 6,
   ST_ERR_ITER = 7,
+  ST_ERR_GAPS_OVERFLOW = 8,
   ST_COUNT = 16
 };
 
@@ -49,10 +50,16 @@ struct GraphDev {
   u32 *l0_ids;   // [n][M0], HNY_SENT beyond the count
   float *l0_dist; // [n][M0]
   u32 *l0_cnt;   // [n] low 16 bits = count, bit 31 = frozen (full and self-pruned to full)
-  u32 *up_ids;   // [n_upper][max_level][M]
+  u32 *up_ids;   // [n_upper][up_layers][M]
   float *up_dist;
-  u32 *up_cnt;   // [n_upper][max_level]
+  u32 *up_cnt;   // [n_upper][up_layers]
   u64 *stats;    // [ST_COUNT]
+  u32 up_layers; // upper layers that have storage (== max(max_level,1) for a fresh build)
+  // incremental builds: the previous graph as stored in LMDB (read-only) + which items still exist
+  int incremental;
+  const u32 *d0_ids;            // [n][M0] old layer-0 Links, ascending, HNY_SENT padded
+  const u32 *du_ids;            // [n_upper][up_layers][M]
+  const unsigned char *has_vec; // [n] 0 = deleted item (no Item record any more)
 };
 
 struct WalkArgs {
@@ -134,5 +141,8 @@ hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *ke
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st);
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);
+// fill_gaps_from_deleted (hnsw.rs:334-415) for the old records rec[i] = layer << 31 | slot
+hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
+                          LaunchShape s, hipStream_t st);
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st);
 size_t hnyk_walk_lds_bytes(u32 rcap);

@@ -300,7 +300,18 @@ __device__ __forceinline__ const u32 *nbr_ids(const GraphDev &g, u32 layer, u32 
   }
   int ui = g.upper_idx[node];
   cap = g.M;
-  return g.up_ids + ((size_t)ui * g.max_level + (layer - 1)) * g.M;
+  return g.up_ids + ((size_t)ui * g.up_layers + (layer - 1)) * g.M;
+}
+// on-disk Links of the previous build (incremental only); null when the node has no such layer
+__device__ __forceinline__ const u32 *disk_ids(const GraphDev &g, u32 layer, u32 node, u32 &cap) {
+  if (layer == 0) {
+    cap = g.M0;
+    return g.d0_ids + (size_t)node * g.M0;
+  }
+  cap = g.M;
+  int ui = g.upper_idx[node];
+  if (ui < 0 || layer > g.up_layers) return nullptr;
+  return g.du_ids + ((size_t)ui * g.up_layers + (layer - 1)) * g.M;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,54 +575,63 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
     }
     const float fmax = __uint_as_float(dmax); // f_max captured once per pop (:484)
 
-    // ---- neighbours of c (:491-495)
-    u32 cap;
-    const u32 *nl = nbr_ids(g, layer, cslot, cap);
-    u32 id = (u32)ln < cap ? nl[ln] : HNY_SENT;
-    bool valid = id != HNY_SENT;
-    bool isnew = visited_insert(vis, id, valid);
-    u64 nmask = __ballot(isnew);
-    if (!nmask) continue;
-    if (s.res_len < ef) {
-      // duplicates inside one list (add_link never dedups, hnsw.rs:521): while res is not full
-      // the order of acceptance matters, so the FIRST occurrence must be the one that counts
-      nb_ids[ln] = valid ? id : HNY_SENT;
-      WSYNC();
-      int firstj = ln;
-      bool anynew = isnew;
-      for (int j = 0; j < (int)cap; j++) {
-        u32 oj = nb_ids[j];
-        if (valid && oj == id) {
-          if (j < firstj) firstj = j;
-          if ((nmask >> j) & 1ull) anynew = true;
-        }
+    // ---- neighbours of c (:491-495): on-disk Links first (incremental builds, :438-441), then the
+    // in-memory list
+    for (int pass = g.incremental ? 0 : 1; pass < 2; pass++) {
+      u32 cap;
+      const u32 *nl = pass == 0 ? disk_ids(g, layer, cslot, cap) : nbr_ids(g, layer, cslot, cap);
+      if (!nl) continue;
+      u32 id = (u32)ln < cap ? nl[ln] : HNY_SENT;
+      bool valid = id != HNY_SENT;
+      bool isnew = visited_insert(vis, id, valid);
+      u64 nmask = __ballot(isnew);
+      if (!nmask) continue;
+      visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+      if (g.incremental) { // MissingKey => the item was deleted: visited, but never scored (:498-502)
+        isnew = isnew && g.has_vec[id] != 0;
+        nmask = __ballot(isnew);
+        if (!nmask) continue;
       }
-      isnew = valid && anynew && firstj == ln;
+      if (s.res_len < ef) {
+        // duplicates inside one list (add_link never dedups, hnsw.rs:521): while res is not full
+        // the order of acceptance matters, so the FIRST occurrence must be the one that counts
+        nb_ids[ln] = valid ? id : HNY_SENT;
+        WSYNC();
+        int firstj = ln;
+        bool anynew = isnew;
+        for (int j = 0; j < (int)cap; j++) {
+          u32 oj = nb_ids[j];
+          if (valid && oj == id) {
+            if (j < firstj) firstj = j;
+            if ((nmask >> j) & 1ull) anynew = true;
+          }
+        }
+        isnew = valid && anynew && firstj == ln;
+        WSYNC();
+        nmask = __ballot(isnew);
+      }
+      const int n_new = __popcll(nmask);
+      const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
+      if (isnew) nb_ids[rank] = id;
       WSYNC();
-      nmask = __ballot(isnew);
-    }
-    const int n_new = __popcll(nmask);
-    const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
-    visited_log(vis, id, isnew, nmask, rank);
-    if (isnew) nb_ids[rank] = id;
-    WSYNC();
-    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d); // :503
-    evals += (u64)n_new;
-    WSYNC();
-    const float myd = ln < n_new ? nb_d[ln] : 0.f;
-    const u32 myid = ln < n_new ? nb_ids[ln] : 0u;
-    int room = ef - s.res_len;
-    if (room < 0) room = 0;
-    // :505 `res.len() < ef || dist < f_max` — the first `room` new points are taken regardless
-    bool acc = ln < n_new && (ln < room || myd < fmax);
-    u64 amask = __ballot(acc);
-    WSYNC();
-    while (amask) {
-      int r = __ffsll((long long)amask) - 1;
-      amask &= amask - 1ull;
-      u32 db = (u32)__builtin_amdgcn_readlane((int)fbits(myd), r);
-      u32 idr = (u32)__builtin_amdgcn_readlane((int)myid, r);
-      beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
+      dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d); // :503
+      evals += (u64)n_new;
+      WSYNC();
+      const float myd = ln < n_new ? nb_d[ln] : 0.f;
+      const u32 myid = ln < n_new ? nb_ids[ln] : 0u;
+      int room = ef - s.res_len;
+      if (room < 0) room = 0;
+      // :505 `res.len() < ef || dist < f_max` — the first `room` new points are taken regardless
+      bool acc = ln < n_new && (ln < room || myd < fmax);
+      u64 amask = __ballot(acc);
+      WSYNC();
+      while (amask) {
+        int r = __ffsll((long long)amask) - 1;
+        amask &= amask - 1ull;
+        u32 db = (u32)__builtin_amdgcn_readlane((int)fbits(myd), r);
+        u32 idr = (u32)__builtin_amdgcn_readlane((int)myid, r);
+        beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
+      }
     }
   }
 }
@@ -1063,7 +1083,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
       dist = g.l0_dist + (size_t)target * g.M0;
       cntp = g.l0_cnt + target;
     } else { // :534 `layers.get(level)` — the target always has this layer (it was found on it)
-      size_t u = (size_t)g.upper_idx[target] * g.max_level + (layer - 1);
+      size_t u = (size_t)g.upper_idx[target] * g.up_layers + (layer - 1);
       cap = g.M;
       ids = g.up_ids + u * g.M;
       dist = g.up_dist + u * g.M;
@@ -1152,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int S
       dist = g.l0_dist + (size_t)target * g.M0;
       cntp = g.l0_cnt + target;
     } else {
-      size_t u = (size_t)g.upper_idx[target] * g.max_level + (layer - 1);
+      size_t u = (size_t)g.upper_idx[target] * g.up_layers + (layer - 1);
       cap = g.M;
       ids = g.up_ids + u * g.M;
       dist = g.up_dist + u * g.M;
@@ -1199,6 +1219,147 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int S
     __syncthreads();
   }
   if ((tid & 63) == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
+}
+
+// fill_gaps_from_deleted (hnsw.rs:334-415), one wave per surviving old record (layer, slot):
+//   bm = (old links  U  old links of every DELETED old neighbour)  -  deleted       (:382-388)
+//   |bm| + |new| <= cap :  list = [(0.0, j) for j in bm ascending] ++ new           (:391-400)
+//   else               :  list = robust_prune(new ++ [(d(slot, j), j) for j in bm]) (:403-410)
+#define HNY_GAPS_MAXU 1024
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u32 n_recs,
+                                                  const unsigned char *deleted) {
+  __shared__ u32 cand[HNY_GAPS_MAXU];
+  __shared__ u32 bm[HNY_GAPS_MAXU];
+  __shared__ u64 keys[HNY_GAPS_MAXU + HNY_MAX_CAP];
+  __shared__ u64 sorted[HNY_GAPS_MAXU + HNY_MAX_CAP];
+  __shared__ u64 S[HNY_MAX_CAP];
+  __shared__ u32 s_ids[HNY_MAX_CAP];
+  __shared__ float tmp_d[64];
+  const int ln = threadIdx.x, t = ln % LPR;
+  u64 evals = 0;
+  u32 overflow = 0;
+  for (u32 ri = blockIdx.x; ri < n_recs; ri += gridDim.x) {
+    const u64 rec = recs[ri];
+    const u32 layer = (u32)(rec >> 31), slot = (u32)(rec & 0x7FFFFFFFull);
+    u32 cap, dcap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)slot * g.M0;
+      dist = g.l0_dist + (size_t)slot * g.M0;
+      cntp = g.l0_cnt + slot;
+    } else {
+      size_t u = (size_t)g.upper_idx[slot] * g.up_layers + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    const int cnt = (int)(*cntp & 0xFFFFu);
+    const u32 *dl = disk_ids(g, layer, slot, dcap);
+    // ---- gather: own old links + the old links of deleted old neighbours
+    int nu = 0;
+    for (u32 j = 0; j < dcap; j++) {
+      const u32 x = uni(dl[j]);
+      if (x == HNY_SENT) break;
+      if (nu < HNY_GAPS_MAXU && ln == 0) cand[nu] = x;
+      nu++;
+      if (deleted[x]) {
+        u32 c2;
+        const u32 *xl = disk_ids(g, layer, x, c2);
+        if (xl) {
+          const u32 y = (u32)ln < c2 ? xl[ln] : HNY_SENT;
+          const bool v = y != HNY_SENT;
+          const u64 m = __ballot(v);
+          const int pos = nu + __popcll(m & ((1ull << ln) - 1ull));
+          if (v && pos < HNY_GAPS_MAXU) cand[pos] = y;
+          nu += __popcll(m);
+        }
+      }
+    }
+    if (nu > HNY_GAPS_MAXU) {
+      overflow++;
+      continue;
+    }
+    WSYNC();
+    // ---- drop deleted ids and repeats, sort ascending (rank among the kept ones)
+    for (int e = ln; e < nu; e += 64) {
+      const u32 v = cand[e];
+      bool keep = deleted[v] == 0;
+      for (int k2 = 0; k2 < e && keep; k2++) keep = (cand[k2] & 0x7FFFFFFFu) != v;
+      if (!keep) cand[e] = v | 0x80000000u;
+    }
+    WSYNC();
+    int nb = 0;
+    for (int base = 0; base < nu; base += 64) {
+      const int e = base + ln;
+      const bool kept = e < nu && !(cand[e] >> 31);
+      if (kept) {
+        const u32 v = cand[e];
+        int pos = 0;
+        for (int k2 = 0; k2 < nu; k2++) {
+          const u32 o = cand[k2];
+          pos += (!(o >> 31) && o < v) ? 1 : 0;
+        }
+        bm[pos] = v;
+      }
+      nb += __popcll(__ballot(kept));
+    }
+    WSYNC();
+    const u32 oi = ln < cnt ? ids[ln] : HNY_SENT;
+    const float od = ln < cnt ? dist[ln] : 0.f;
+    if (nb + cnt <= (int)cap) { // :391-400 distances are "no longer relevant": 0.0
+      WSYNC();
+      if (ln < nb) {
+        ids[ln] = bm[ln];
+        dist[ln] = 0.f;
+      }
+      if (ln < cnt) {
+        ids[nb + ln] = oi;
+        dist[nb + ln] = od;
+      }
+      if (ln == 0) *cntp = (u32)(nb + cnt);
+      WSYNC();
+      continue;
+    }
+    // ---- :403-410 score the old links and prune old + new together
+    float4 q[NCH];
+    load_row<LPR, NCH>(g.rows + (size_t)slot * g.row_stride, t, g.n16, q);
+    const float qn = g.norms ? g.norms[slot] : 0.f;
+    if (ln < cnt) keys[ln] = ((u64)fbits(od) << 32) | oi;
+    for (int base = 0; base < nb; base += 64) {
+      const int c = nb - base < 64 ? nb - base : 64;
+      dist_rows<LPR, NCH>(g, q, qn, bm + base, c, tmp_d);
+      evals += (u64)c;
+      WSYNC();
+      if (ln < c) keys[cnt + base + ln] = ((u64)fbits(tmp_d[ln]) << 32) | bm[base + ln];
+      WSYNC();
+    }
+    const int n = cnt + nb;
+    for (int e = ln; e < n; e += 64) {
+      const u64 mine = keys[e];
+      int rk = 0;
+      for (int k2 = 0; k2 < n; k2++) {
+        const u64 o = keys[k2];
+        rk += (o < mine || (o == mine && k2 < e)) ? 1 : 0;
+      }
+      sorted[rk] = mine;
+    }
+    WSYNC();
+    const int s_len = wave_prune<LPR, NCH>(g, sorted, n, (int)cap, S, s_ids, tmp_d, evals);
+    if ((u32)ln < cap) {
+      const bool on = ln < s_len;
+      ids[ln] = on ? (u32)(S[ln] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[ln] = on ? __uint_as_float((u32)(S[ln] >> 32)) : 0.f;
+    }
+    if (ln == 0) *cntp = (u32)s_len;
+    WSYNC();
+  }
+  if (ln == 0) {
+    if (evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
+    if (overflow) atomicAdd(&g.stats[ST_ERR_GAPS_OVERFLOW], (u64)overflow);
+  }
 }
 
 // D::distance for explicit pairs of stored items (tests / parity checks)
@@ -1313,6 +1474,15 @@ struct ApplyLauncher {
   }
 };
 template <int L, int C>
+struct GapsLauncher {
+  static hipError_t run(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
+                        hipStream_t st) {
+    int grid = n_recs < 16384u ? (int)n_recs : 16384;
+    hipLaunchKernelGGL((k_fill_gaps<L, C>), dim3(grid), dim3(64), 0, st, g, recs, n_recs, deleted);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
 struct PairLauncher {
   static hipError_t run(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                         hipStream_t st) {
@@ -1349,6 +1519,11 @@ hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, i
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st) {
   return dispatch_shape<PairLauncher>(s, g, a, b, n, out, st);
+}
+hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
+                          LaunchShape s, hipStream_t st) {
+  if (!n_recs) return hipSuccess;
+  return dispatch_shape<GapsLauncher>(s, g, recs, n_recs, deleted, st);
 }
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st) {
   u64 total = (u64)a.count * (a.batch_level + 1) * a.cap_sel;

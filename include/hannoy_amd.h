@@ -116,6 +116,27 @@ typedef struct {
 int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **out);
 void hny_graph_free(hny_graph *g);
 
+/* ---- incremental build: HnswBuilder::build on a non-empty index (hnsw.rs:122-216 with
+ * prepare_levels_and_entry_points' deletion branch :236-289, on-disk links in get_neighbours
+ * :438-441, fill_gaps_from_deleted :334-415) + delete_links_from_db (writer.rs:692-718).
+ * `items`: every item that exists AFTER the update (item_indices, writer.rs:548-553; deleted items
+ * gone, overwritten items with their new vector); items->levels, if given, holds one level per
+ * to_insert id.  `prev`: what FrozenReader::links / iter_links and the Metadata record yield.
+ * The result is the complete set of Links records after the build. ---- */
+typedef struct {
+  uint64_t n_records;
+  const uint32_t *rec_item;
+  const uint8_t *rec_layer;
+  const uint64_t *rec_offset;
+  const uint32_t *neighbours;
+  const uint32_t *entry_points;
+  uint32_t n_entry_points;
+  uint32_t max_level;
+} hny_prev_graph;
+int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
+                          uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
+                          const hny_prev_graph *prev, hny_graph **out);
+
 /* ---- stepwise build (what hny_build loops over; used by the multi-GPU driver) ---- */
 int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out);
 int hny_builder_reset(hny_builder *b); /* empty graph again, vectors stay resident in HBM */

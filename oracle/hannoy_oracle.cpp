@@ -713,6 +713,106 @@ uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap) {
   return level;
 }
 
+/* hnsw.rs:160-185: level groups in order; inside a group either the reference's plain insertion
+ * (1 thread or rayon-like) or the batch-synchronous schedule of the GPU build */
+static void run_schedule(Builder &B, const orc_opts *opts,
+                         const std::vector<std::pair<uint32_t, uint32_t>> &ord, uint64_t n_done,
+                         std::vector<Scratch> &scratch, uint64_t &evals, uint64_t &links) {
+  const size_t n = ord.size();
+  size_t pos = 0;
+  const int nthreads = (int)scratch.size();
+
+  while (pos < n) {
+    /* hnsw.rs:160 chunk_by level */
+    size_t gend = pos;
+    while (gend < n && ord[gend].second == ord[pos].second) gend++;
+
+    if (opts->batch_max == 0) {
+      if (nthreads == 1) {
+        Scratch &S = scratch[0];
+        for (size_t i = pos; i < gend; i++) {
+          uint32_t q = ord[i].first, lvl = ord[i].second;
+          Selection sel;
+          /* NB: registration precedes the walks in the reference (:309), harmless here */
+          insert_search(B, S, q, lvl, sel);
+          register_item(B, q, lvl);
+          insert_apply(B, q, lvl, sel, S.evals, links);
+        }
+      } else {
+        /* rayon-like: grp.into_par_iter().try_for_each(insert) :172-185 */
+        std::atomic<size_t> next{pos};
+        std::vector<std::thread> th;
+        std::vector<uint64_t> tlinks(nthreads, 0);
+        for (int t = 0; t < nthreads; t++)
+          th.emplace_back([&, t]() {
+            Scratch &S = scratch[t];
+            for (;;) {
+              size_t i = next.fetch_add(1);
+              if (i >= gend) break;
+              uint32_t q = ord[i].first, lvl = ord[i].second;
+              /* the reference interleaves walk/prune/link per layer; with concurrent threads the
+               * per-layer interleaving is kept so that lower walks see this item's upper links */
+              std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end());
+              auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
+              std::vector<Link> res, sel;
+              for (uint32_t l = B.max_level; l > lvl; l--) {
+                walk_layer(B, S, qd, eps, l, 1, res);
+                eps.assign(1, res.front().id);
+              }
+              register_item(B, q, lvl);
+              for (int32_t l = (int32_t)lvl; l >= 0; l--) {
+                walk_layer(B, S, qd, eps, (uint32_t)l, B.o.ef_construction, res);
+                robust_prune(B, res, B.cap(lvl), S.evals, sel);
+                eps.clear();
+                for (const Link &s : sel) {
+                  add_link(B, q, s, (uint32_t)l, S.evals);
+                  add_link(B, s.id, Link{s.d, q}, (uint32_t)l, S.evals);
+                  eps.push_back(s.id);
+                  tlinks[t] += 2;
+                }
+              }
+            }
+          });
+        for (auto &t : th) t.join();
+        for (uint64_t v : tlinks) links += v;
+      }
+      n_done += gend - pos;
+      pos = gend;
+    } else {
+      /* batch-synchronous schedule: every member of a batch searches the same frozen graph,
+       * then links are applied in batch order (DESIGN.md "Batch semantics") */
+      size_t bsz = orc_batch_size(opts->batch_frac, opts->batch_max, n_done);
+      size_t bend = std::min(gend, pos + bsz);
+      size_t cnt = bend - pos;
+      std::vector<Selection> sels(cnt);
+      if (nthreads == 1) {
+        for (size_t i = 0; i < cnt; i++)
+          insert_search(B, scratch[0], ord[pos + i].first, ord[pos + i].second, sels[i]);
+      } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+          th.emplace_back([&, t]() {
+            for (;;) {
+              size_t i = next.fetch_add(1);
+              if (i >= cnt) break;
+              insert_search(B, scratch[t], ord[pos + i].first, ord[pos + i].second, sels[i]);
+            }
+          });
+        for (auto &t : th) t.join();
+      }
+      bool was_threaded = B.threaded;
+      B.threaded = false; /* apply is sequential by definition */
+      for (size_t i = 0; i < cnt; i++) register_item(B, ord[pos + i].first, ord[pos + i].second);
+      for (size_t i = 0; i < cnt; i++)
+        insert_apply(B, ord[pos + i].first, ord[pos + i].second, sels[i], evals, links);
+      B.threaded = was_threaded;
+      n_done += cnt;
+      pos = bend;
+    }
+  }
+}
+
 /* [3P] rand_chacha 0.3 ChaCha12Rng (rand 0.8.5 StdRng): 12 rounds, 64-bit block counter in words
  * 12-13, stream id 0, output = successive blocks, words in order. */
 namespace {
@@ -845,99 +945,12 @@ int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
   }
 
   uint64_t evals = 0, links = 0;
-  size_t pos = 0;
-  uint64_t n_done = 0;
   int nthreads = std::max(1, opts->threads);
   std::vector<Scratch> scratch(nthreads);
-
-  while (pos < n) {
-    /* hnsw.rs:160 chunk_by level */
-    size_t gend = pos;
-    while (gend < n && B.level[order[gend]] == B.level[order[pos]]) gend++;
-
-    if (opts->batch_max == 0) {
-      if (nthreads == 1) {
-        Scratch &S = scratch[0];
-        for (size_t i = pos; i < gend; i++) {
-          uint32_t q = order[i], lvl = B.level[q];
-          Selection sel;
-          /* NB: registration precedes the walks in the reference (:309), harmless here */
-          insert_search(B, S, q, lvl, sel);
-          register_item(B, q, lvl);
-          insert_apply(B, q, lvl, sel, S.evals, links);
-        }
-      } else {
-        /* rayon-like: grp.into_par_iter().try_for_each(insert) :172-185 */
-        std::atomic<size_t> next{pos};
-        std::vector<std::thread> th;
-        std::vector<uint64_t> tlinks(nthreads, 0);
-        for (int t = 0; t < nthreads; t++)
-          th.emplace_back([&, t]() {
-            Scratch &S = scratch[t];
-            for (;;) {
-              size_t i = next.fetch_add(1);
-              if (i >= gend) break;
-              uint32_t q = order[i], lvl = B.level[q];
-              /* the reference interleaves walk/prune/link per layer; with concurrent threads the
-               * per-layer interleaving is kept so that lower walks see this item's upper links */
-              std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end());
-              auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
-              std::vector<Link> res, sel;
-              for (uint32_t l = B.max_level; l > lvl; l--) {
-                walk_layer(B, S, qd, eps, l, 1, res);
-                eps.assign(1, res.front().id);
-              }
-              register_item(B, q, lvl);
-              for (int32_t l = (int32_t)lvl; l >= 0; l--) {
-                walk_layer(B, S, qd, eps, (uint32_t)l, B.o.ef_construction, res);
-                robust_prune(B, res, B.cap(lvl), S.evals, sel);
-                eps.clear();
-                for (const Link &s : sel) {
-                  add_link(B, q, s, (uint32_t)l, S.evals);
-                  add_link(B, s.id, Link{s.d, q}, (uint32_t)l, S.evals);
-                  eps.push_back(s.id);
-                  tlinks[t] += 2;
-                }
-              }
-            }
-          });
-        for (auto &t : th) t.join();
-        for (uint64_t v : tlinks) links += v;
-      }
-      n_done += gend - pos;
-      pos = gend;
-    } else {
-      /* batch-synchronous schedule: every member of a batch searches the same frozen graph,
-       * then links are applied in batch order (DESIGN.md "Batch semantics") */
-      size_t bsz = orc_batch_size(opts->batch_frac, opts->batch_max, n_done);
-      size_t bend = std::min(gend, pos + bsz);
-      size_t cnt = bend - pos;
-      std::vector<Selection> sels(cnt);
-      if (nthreads == 1) {
-        for (size_t i = 0; i < cnt; i++)
-          insert_search(B, scratch[0], order[pos + i], B.level[order[pos + i]], sels[i]);
-      } else {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; t++)
-          th.emplace_back([&, t]() {
-            for (;;) {
-              size_t i = next.fetch_add(1);
-              if (i >= cnt) break;
-              insert_search(B, scratch[t], order[pos + i], B.level[order[pos + i]], sels[i]);
-            }
-          });
-        for (auto &t : th) t.join();
-      }
-      bool was_threaded = B.threaded;
-      B.threaded = false; /* apply is sequential by definition */
-      for (size_t i = 0; i < cnt; i++) register_item(B, order[pos + i], B.level[order[pos + i]]);
-      for (size_t i = 0; i < cnt; i++)
-        insert_apply(B, order[pos + i], B.level[order[pos + i]], sels[i], evals, links);
-      B.threaded = was_threaded;
-      n_done += cnt;
-      pos = bend;
-    }
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> ord(n);
+    for (uint32_t i = 0; i < n; i++) ord[i] = {order[i], B.level[order[i]]};
+    run_schedule(B, opts, ord, 0, scratch, evals, links);
   }
   for (auto &s : scratch) evals += s.evals;
 
@@ -1091,31 +1104,19 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
   for (uint32_t s = 0; s < n; s++)
     if (in_new[s]) B.entry_points.push_back(s); /* :287 */
 
-  /* hnsw.rs:172-185 with one thread */
-  Scratch S;
-  uint64_t links = 0;
-  for (auto &pr : levels) {
-    uint32_t q = pr.first, lvl = pr.second;
-    std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end());
-    auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
-    std::vector<Link> res, sel;
-    for (uint32_t l = B.max_level; l > lvl; l--) {
-      walk_layer(B, S, qd, eps, l, 1, res);
-      eps.assign(1, res.front().id);
-    }
-    register_item(B, q, lvl); /* :309 */
-    for (int32_t l = (int32_t)lvl; l >= 0; l--) {
-      walk_layer(B, S, qd, eps, (uint32_t)l, B.o.ef_construction, res);
-      robust_prune(B, res, B.cap(lvl), S.evals, sel);
-      eps.clear();
-      for (const Link &sl : sel) {
-        add_link(B, q, sl, (uint32_t)l, S.evals);
-        add_link(B, sl.id, Link{sl.d, q}, (uint32_t)l, S.evals);
-        eps.push_back(sl.id);
-        links += 2;
-      }
-    }
-  }
+  /* hnsw.rs:172-185; the schedule counts the surviving old layer-0 records as already inserted */
+  uint64_t n_done0 = 0;
+  for (uint32_t s = 0; s < n; s++)
+    if (B.has_disk[0][s] && !del[s]) n_done0++;
+  int nthreads = std::max(1, opts->threads);
+  std::vector<Scratch> scratch(nthreads);
+  uint64_t evals = 0, links = 0;
+  B.threaded = opts->threads > 1;
+  run_schedule(B, opts, levels, n_done0, scratch, evals, links);
+  B.threaded = false;
+  Scratch &S = scratch[0];
+  S.evals += evals;
+  for (int t = 1; t < nthreads; t++) S.evals += scratch[t].evals;
 
   /* fill_gaps_from_deleted, hnsw.rs:334-415 */
   {

@@ -152,3 +152,79 @@ def test_cancel_and_progress(hny):
     assert seen and seen[-1] == (3000, 3000) and all(a[0] <= b[0] for a, b in zip(seen, seen[1:]))
     with pytest.raises(hny.BuildCancelled):
         hny.build(items, M=8, M0=16, ef_construction=32, cancel=lambda: True)
+
+
+def test_kat2_3_4_incremental_on_gpu(kat, orc, hny):
+    """Overwrite / delete / delete again on top of the KAT-1 index: the reference's snapshots."""
+    def links(g):
+        return [[int(i), int(l), nb] for (i, l), nb in sorted(g.as_dict().items())]
+    k1 = kat["kat1"]
+    v = np.array(k1["vectors"], np.float32)
+    ds1, items1 = _mk(orc, hny, 1, v, k1["levels"])
+    g1 = hny.build(items1, M=3, M0=3, ef_construction=100, batch_max=1)
+    k2 = kat["kat2"]
+    v2 = v.copy()
+    v2[3] = k2["overwrite"]["vector"]
+    for lv in k2["insert_levels_any_of"]:
+        it2 = hny.ItemSet.from_f32(hny.EUCLIDEAN, v2, levels=np.array(lv, np.uint8))
+        g2 = hny.build_incremental(it2, g1, k2["to_insert"], k2["to_delete"], M=3, M0=3,
+                                   ef_construction=100, batch_max=1)
+        assert g2.entry_points.tolist() == k2["entry_points"] and links(g2) == k2["links"]
+    k3, k4 = kat["kat3"], kat["kat4"]
+    keep = np.array([0, 1, 2, 4, 5], np.uint32)
+    it3 = hny.ItemSet.from_f32(hny.EUCLIDEAN, v[keep], ids=keep)
+    g3 = hny.build_incremental(it3, g1, [], k3["to_delete"], M=3, M0=3, ef_construction=100, batch_max=1)
+    assert g3.entry_points.tolist() == k3["entry_points"] and g3.max_level == 1
+    assert links(g3) == k3["links"]
+    keep = np.array([0, 2, 4, 5], np.uint32)
+    it4 = hny.ItemSet.from_f32(hny.EUCLIDEAN, v[keep], ids=keep)
+    g4 = hny.build_incremental(it4, g3, [], k4["to_delete"], M=3, M0=3, ef_construction=100, batch_max=1)
+    assert g4.entry_points.tolist() == k4["entry_points"] and links(g4) == k4["links"]
+
+
+@pytest.mark.parametrize("metric,dim,M,M0,ef,frac,bmax", [(1, 24, 6, 12, 32, 0.0, 1), (0, 48, 8, 16, 40, 0.1, 64),
+                                                           (3, 128, 8, 16, 24, 0.1, 32)])
+def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac, bmax):
+    """Two rounds of random deletes / overwrites / additions: GPU == oracle edge for edge."""
+    rng = np.random.default_rng(dim + M)
+    n0 = 1500
+    vecs = {i: rng.uniform(-1, 1, dim).astype(np.float32) for i in range(n0)}
+    kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax)
+    kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+
+    def mk(ids, levels):
+        ids = np.array(sorted(ids), np.uint32)
+        mat = np.stack([vecs[int(i)] for i in ids])
+        ds = orc.Dataset.from_f32(metric, mat, levels if levels is not None else np.zeros(len(ids), np.uint8), ids)
+        return ds
+    ds = mk(vecs.keys(), draw_levels(n0, M, seed=1))
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    og = orc.build(ds, **kw_o)
+    gg = hny.build(items, **kw_g)
+    _same_graph(gg, og)
+    next_id = n0
+    for rnd in range(2):
+        alive = sorted(vecs.keys())
+        to_delete = sorted(rng.choice(alive, 120, replace=False).tolist())
+        for i in to_delete:
+            del vecs[i]
+        alive = sorted(vecs.keys())
+        overwrite = sorted(rng.choice(alive, 40, replace=False).tolist())
+        for i in overwrite:
+            vecs[i] = rng.uniform(-1, 1, dim).astype(np.float32)
+        added = list(range(next_id, next_id + 200))
+        next_id += 200
+        for i in added:
+            vecs[i] = rng.uniform(-1, 1, dim).astype(np.float32)
+        to_insert = sorted(overwrite + added)
+        ins_levels = draw_levels(len(to_insert), M, seed=10 + rnd)
+        ds = mk(vecs.keys(), None)
+        items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ins_levels)
+        og = orc.build_incremental(ds, og, to_insert, ins_levels, to_delete, **kw_o)
+        gg = hny.build_incremental(items, gg, to_insert, to_delete, **kw_g)
+        _same_graph(gg, og)
+        # validity: no link to a deleted item, every item owns a layer-0 record
+        d = gg.as_dict()
+        alive_set = set(vecs.keys())
+        assert all(set(nb) <= alive_set for nb in d.values())
+        assert {i for (i, l) in d if l == 0} == alive_set
