@@ -175,6 +175,22 @@ def main():
                 "algorithmic_bytes_per_launch": int(walk_bytes / max(1, graph.n_walk_launches)),
                 "bytes_per_eval": bytes_per_eval}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
+    # the figure comes from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch
+    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_tuned.json")
+    default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
+                  and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
+                  and world == 1)
+    if roof and default_c2 and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            pk = json.load(f).get("k_walk")
+        if pk:
+            roof["traffic"] = int(pk["hbm_bytes_per_launch"])
+            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_tuned.json: rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command, 2x FETCH + WRITE, "
+                                      f"{pk['launches']} k_walk launches")
+
     out = {
         "metric": "vectors indexed/sec (build) + recall@10, 1M x 768 Cosine M=16 efC=100",
         "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": a.steps,

@@ -231,6 +231,10 @@ struct hny_builder {
   uint32_t bmax = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;          // prune of chunk i overlaps the walk of chunk i+1
+  std::vector<hipEvent_t> sync_evs;       // cross-stream dependencies (no timing)
+  size_t sync_used = 0;
+  bool overlap = true;
   // schedule state
   size_t pos = 0;
   uint64_t n_done = 0, n_batches = 0;
@@ -263,6 +267,8 @@ struct hny_builder {
   size_t ev_used = 0;
   bool profiling = false;
   ~hny_builder() {
+    for (auto &e : sync_evs) (void)hipEventDestroy(e);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (h_l0) (void)hipHostFree(h_l0);
     if (h_up) (void)hipHostFree(h_up);
     if (h_cnt0) (void)hipHostFree(h_cnt0);
@@ -274,8 +280,9 @@ struct hny_builder {
   }
 };
 enum { EV_WALK = 0, EV_PRUNE = 1, EV_SORT = 2, EV_APPLY = 3, EV_KINDS = 4 };
-static void prof_begin(hny_builder *b, int kind) {
+static void prof_begin(hny_builder *b, int kind, hipStream_t st = nullptr) {
   if (!b->profiling) return;
+  if (!st) st = b->stream;
   if (b->ev_used == b->evs.size()) {
     hny_builder::Ev e{};
     e.kind = kind;
@@ -283,11 +290,12 @@ static void prof_begin(hny_builder *b, int kind) {
     b->evs.push_back(e);
   }
   b->evs[b->ev_used].kind = kind;
-  (void)hipEventRecord(b->evs[b->ev_used].a, b->stream);
+  (void)hipEventRecord(b->evs[b->ev_used].a, st);
 }
-static void prof_end(hny_builder *b) {
+static void prof_end(hny_builder *b, hipStream_t st = nullptr) {
   if (!b->profiling || b->ev_used >= b->evs.size()) return;
-  (void)hipEventRecord(b->evs[b->ev_used].b, b->stream);
+  if (!st) st = b->stream;
+  (void)hipEventRecord(b->evs[b->ev_used].b, st);
   b->ev_used++;
 }
 
@@ -368,6 +376,7 @@ int reset_graph(hny_builder *b) {
   b->in_batch = false;
   b->finalized = false;
   b->ev_used = 0;
+  b->sync_used = 0;
   b->t_build0 = now_s();
   return HNY_OK;
 }
@@ -459,6 +468,7 @@ void hny_builder_destroy(hny_builder *b) {
   if (b->stream) {
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
+    if (b->stream2) (void)hipStreamSynchronize(b->stream2);
     (void)hipStreamDestroy(b->stream);
   }
   delete b;
@@ -516,6 +526,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     HIP_TRY(hipGetDevice(&b->device));
   }
   HIP_TRY(hipStreamCreate(&b->stream));
+  HIP_TRY(hipStreamCreate(&b->stream2));
+  b->overlap = env_int("HNY_OVERLAP", 0) != 0; // measured slower (prune WGs compete with the walk for LDS/VGPRs)
   hipStream_t st = b->stream;
   double t0 = now_s();
 
@@ -746,7 +758,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_vals_a.alloc(b->max_ops));
   HIP_TRY(b->d_vals_b.alloc(b->max_ops));
   HIP_TRY(b->d_seg_start.alloc(b->max_ops));
-  HIP_TRY(b->d_nseg.alloc(4));
+  HIP_TRY(b->d_nseg.alloc(16));
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, (u32)b->max_ops, st));
@@ -870,6 +882,17 @@ int hny_builder_next_batch(hny_builder *b, hny_batch *out) {
   return HNY_OK;
 }
 
+static hipError_t next_sync_event(hny_builder *b, hipEvent_t *ev) {
+  if (b->sync_used == b->sync_evs.size()) {
+    hipEvent_t e;
+    hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return rc;
+    b->sync_evs.push_back(e);
+  }
+  *ev = b->sync_evs[b->sync_used++];
+  return hipSuccess;
+}
+
 int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) {
   if (!b || !b->in_batch) return fail(HNY_ERR_INVALID_ARG, "no current batch");
   if (lo > hi || hi > b->cur.count) return fail(HNY_ERR_INVALID_ARG, "bad member range");
@@ -877,12 +900,11 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   HIP_TRY(hipSetDevice(b->device));
   const uint32_t L = b->cur.level, cs = cap_of(b, L);
   u64 *sel = sel_dev ? (u64 *)sel_dev : b->d_sel.p;
-  const int grid = (int)std::min<uint32_t>(hi - lo, b->walk_slots);
-  for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
+  auto walk_args = [&](int32_t l, uint32_t clo, uint32_t chi, u32 *queue) {
     WalkArgs w{};
     w.q_slots = b->d_order.p + b->cur.first;
-    w.lo = lo;
-    w.hi = hi;
+    w.lo = clo;
+    w.hi = chi;
     w.layer = (u32)l;
     w.ef = b->o.ef_construction;
     w.first = (l == (int32_t)L);
@@ -900,15 +922,14 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
-    w.queue = b->d_nseg.p + 2;
-    HIP_TRY(hipMemsetAsync(w.queue, 0, 4, b->stream));
-    prof_begin(b, EV_WALK);
-    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
-    prof_end(b);
+    w.queue = queue;
+    return w;
+  };
+  auto prune_args = [&](int32_t l, uint32_t clo, uint32_t chi) {
     PruneArgs p{};
-    p.q_slots = w.q_slots;
-    p.lo = lo;
-    p.hi = hi;
+    p.q_slots = b->d_order.p + b->cur.first;
+    p.lo = clo;
+    p.hi = chi;
     p.layer = (u32)l;
     p.cap = cs; // NB: from the item's top level, hnsw.rs:317
     p.cand = b->d_cand.p;
@@ -918,12 +939,52 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     p.sel_stride = b->cur.sel_stride_u64;
     p.cap_sel = cs;
     p.batch_level = L;
-    prof_begin(b, EV_PRUNE);
+    return p;
+  };
+  auto launch_prune = [&](const PruneArgs &p, hipStream_t st) -> hipError_t {
     if (b->wave_prune_only)
-      HIP_TRY(hnyk_prune(b->g, p, b->shape, grid, b->stream));
-    else
-      HIP_TRY(hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, (int)std::min<uint32_t>(hi - lo, 2048),
-                            b->stream));
+      return hnyk_prune(b->g, p, b->shape, (int)std::min<uint32_t>(p.hi - p.lo, b->walk_slots), st);
+    return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
+  };
+  u32 *queues = b->d_nseg.p + 4; // 8 work counters
+  HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
+
+  const uint32_t cnt = hi - lo;
+  if (L == 0 && b->overlap && cnt >= 8192) {
+    // level-0 batch: 4 chunks; walks run back to back on the main stream, the prune of chunk i
+    // runs on stream2 as soon as walk i is done, i.e. under walk i+1 and in walk i's launch tail
+    const uint32_t C = 4, per = (cnt + C - 1) / C;
+    hipEvent_t ev;
+    HIP_TRY(next_sync_event(b, &ev)); // stream2 must not run ahead of the previous apply
+    HIP_TRY(hipEventRecord(ev, b->stream));
+    HIP_TRY(hipStreamWaitEvent(b->stream2, ev, 0));
+    for (uint32_t c = 0; c < C; c++) {
+      const uint32_t clo = lo + c * per, chi = std::min(hi, clo + per);
+      if (clo >= chi) break;
+      WalkArgs w = walk_args(0, clo, chi, queues + c);
+      prof_begin(b, EV_WALK);
+      HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(chi - clo, b->walk_slots), b->stream));
+      prof_end(b);
+      HIP_TRY(next_sync_event(b, &ev));
+      HIP_TRY(hipEventRecord(ev, b->stream));
+      HIP_TRY(hipStreamWaitEvent(b->stream2, ev, 0));
+      prof_begin(b, EV_PRUNE, b->stream2);
+      HIP_TRY(launch_prune(prune_args(0, clo, chi), b->stream2));
+      prof_end(b, b->stream2);
+    }
+    HIP_TRY(next_sync_event(b, &ev));
+    HIP_TRY(hipEventRecord(ev, b->stream2));
+    HIP_TRY(hipStreamWaitEvent(b->stream, ev, 0));
+    return HNY_OK;
+  }
+  const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
+  for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
+    WalkArgs w = walk_args(l, lo, hi, queues + (l & 7));
+    prof_begin(b, EV_WALK);
+    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+    prof_end(b);
+    prof_begin(b, EV_PRUNE);
+    HIP_TRY(launch_prune(prune_args(l, lo, hi), b->stream));
     prof_end(b);
   }
   return HNY_OK;
@@ -1284,7 +1345,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
-    w.queue = b->d_nseg.p + 2;
+    w.queue = b->d_nseg.p + 4;
     HIP_TRY(hipMemsetAsync(w.queue, 0, 4, b->stream));
     HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(cnt, b->walk_slots), b->stream));
     HIP_TRY(hipMemcpyAsync(hc.data(), dcand.p, (size_t)cnt * rcap * 8, hipMemcpyDeviceToHost, b->stream));
