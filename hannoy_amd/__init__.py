@@ -6,5 +6,7 @@ from ._capi import (BQ_COSINE, BQ_EUCLIDEAN, BQ_MANHATTAN, COSINE, EUCLIDEAN, HA
                     METRIC_NAMES, BuildCancelled, Builder, Graph, HannoyError, ItemSet, build, build_incremental, draw_levels,
                     encode_vectors, header_bytes, load_library, make_opts, vector_bytes)
 
-__all__ = ["Builder", "Graph", "ItemSet", "build", "encode_vectors", "load_library", "HannoyError",
+from .api import Database, InvalidVecDimension, Metric, Reader, Writer  # noqa: E402,F401
+
+__all__ = ["Database", "Writer", "Reader", "Metric", "Builder", "Graph", "ItemSet", "build", "encode_vectors", "load_library", "HannoyError",
            "BuildCancelled"]

@@ -25,6 +25,7 @@ EXPORTED = [
     "hny_builder_finish", "hny_builder_destroy", "hny_builder_set_profiling", "hny_batch_size", "hny_builder_distances",
     "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
     "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels", "hny_build_incremental",
+    "hny_builder_create_incremental", "hny_builder_fill_gaps",
 ]
 
 
@@ -105,6 +106,11 @@ def load_library():
     L.hny_build_incremental.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), vp, C.c_uint64, vp,
                                         C.c_uint64, C.POINTER(PrevGraph),
                                         C.POINTER(C.POINTER(GraphStruct))]
+    L.hny_builder_create_incremental.restype = C.c_int
+    L.hny_builder_create_incremental.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), vp, C.c_uint64,
+                                                 vp, C.c_uint64, C.POINTER(PrevGraph), C.POINTER(vp)]
+    L.hny_builder_fill_gaps.restype = C.c_int
+    L.hny_builder_fill_gaps.argtypes = [vp]
     L.hny_builder_create.restype = C.c_int
     L.hny_builder_create.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(vp)]
     for name in ("hny_builder_reset", "hny_builder_sync"):
@@ -277,6 +283,16 @@ def build(items, **kw):
     return Graph(gp, o, items)
 
 
+def _prev_struct(prev):
+    keep = [np.ascontiguousarray(prev.rec_item, np.uint32), np.ascontiguousarray(prev.rec_layer, np.uint8),
+            np.ascontiguousarray(prev.offsets, np.uint64),
+            np.ascontiguousarray(prev.nbrs if len(prev.nbrs) else np.zeros(1), np.uint32),
+            np.ascontiguousarray(prev.entry_points, np.uint32)]
+    pg = PrevGraph(len(keep[0]), _p(keep[0]).value, _p(keep[1]).value, _p(keep[2]).value,
+                   _p(keep[3]).value, _p(keep[4]).value, len(keep[4]), int(prev.max_level))
+    return pg, keep
+
+
 def build_incremental(items, prev, to_insert, to_delete, **kw):
     """hny_build_incremental: `items` = every item present after the update (levels, if any: one per
     to_insert id); `prev` = graph of the previous build (anything with rec_item/rec_layer/offsets/
@@ -300,12 +316,22 @@ def build_incremental(items, prev, to_insert, to_delete, **kw):
 class Builder:
     """Stepwise builder (hny_builder_*): vectors stay resident in HBM across reset()/rebuilds."""
 
-    def __init__(self, items, **kw):
+    def __init__(self, items, prev=None, to_insert=(), to_delete=(), **kw):
+        """prev given -> incremental builder on top of a stored graph (hny_builder_create_incremental)"""
         self.items = items
         self.opts = make_opts(items.metric, items.dim, **kw)
         self._h = C.c_void_p()
+        self.incremental = prev is not None
         it = items.struct()
-        _check(load_library().hny_builder_create(C.byref(self.opts), C.byref(it), C.byref(self._h)))
+        if prev is None:
+            _check(load_library().hny_builder_create(C.byref(self.opts), C.byref(it), C.byref(self._h)))
+        else:
+            ins = np.ascontiguousarray(to_insert, np.uint32)
+            dl = np.ascontiguousarray(to_delete, np.uint32)
+            pg, _keep = _prev_struct(prev)
+            _check(load_library().hny_builder_create_incremental(
+                C.byref(self.opts), C.byref(it), _p(ins), len(ins), _p(dl), len(dl), C.byref(pg),
+                C.byref(self._h)))
 
     def close(self):
         if self._h:
@@ -354,7 +380,12 @@ class Builder:
             self.search(0, b.count)
             self.apply()
             n += 1
+        if self.incremental:
+            self.fill_gaps()
         return n
+
+    def fill_gaps(self):
+        _check(load_library().hny_builder_fill_gaps(self._h))
 
     def finish(self):
         gp = C.POINTER(GraphStruct)()

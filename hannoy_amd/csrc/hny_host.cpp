@@ -1227,6 +1227,21 @@ static int run_fill_gaps(hny_builder *b) {
   return HNY_OK;
 }
 
+int hny_builder_create_incremental(const hny_build_opts *opts, const hny_items *items,
+                                   const uint32_t *to_insert, uint64_t n_insert,
+                                   const uint32_t *to_delete, uint64_t n_delete,
+                                   const hny_prev_graph *prev, hny_builder **out) {
+  IncrementalSpec inc{to_insert, n_insert, to_delete, n_delete, prev};
+  return create_impl(opts, items, &inc, out);
+}
+
+int hny_builder_fill_gaps(hny_builder *b) {
+  if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
+  if (b->pos < b->order.size() || b->in_batch) return fail(HNY_ERR_INVALID_ARG, "build not finished");
+  HIP_TRY(hipSetDevice(b->device));
+  return run_fill_gaps(b);
+}
+
 int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
                           uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
                           const hny_prev_graph *prev, hny_graph **out) {
@@ -1336,6 +1351,8 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.ef = ef;
     w.first = 1;
     w.reader_mode = 1;
+    w.knn_k = k;
+    w.knn_ef = ef_search;
     w.entry_points = b->d_eps.p;
     w.n_entry_points = (u32)b->entry_points.size();
     w.cand = dcand.p;

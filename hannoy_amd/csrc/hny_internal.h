@@ -88,6 +88,8 @@ struct WalkArgs {
   u32 *vlog;        // [grid][log_cap]
   u32 log_cap;
   u32 *queue;       // work counter, zeroed before the launch
+  u32 knn_k;        // reader mode: wanted hits (exhaustive fallback below that, reader.rs:771-795)
+  u32 knn_ef;       // reader mode: opt.ef of the query builder
 };
 
 struct PruneArgs {

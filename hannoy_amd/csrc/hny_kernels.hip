@@ -724,7 +724,61 @@ __global__ __launch_bounds__(64, HNY_WALK_WPE) void k_walk(GraphDev g, WalkArgs 
       u64 k = s.res[e];
       a.cand[(size_t)m * a.rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
     }
-    if (ln == 0) a.cand_n[m] = (u32)s.res_len;
+    int total = s.res_len;
+    if (a.reader_mode && total < (int)a.knn_k) {
+      // Reader::hnsw_search exhaustive fallback (reader.rs:771-795): the walk got trapped in a
+      // sub-graph with fewer than k items; restart from every item not seen yet (ascending id),
+      // sharing the visited set, until opt.ef hits are collected.  Rare; written for clarity.
+      const u32 nwords = (g.n + 31) >> 5;
+      u32 pos = 0;
+      while (pos < g.n) {
+        const u32 wbase = pos >> 5;
+        const u32 widx = wbase + (u32)ln;
+        u32 unv = 0u;
+        if (widx < nwords) {
+          unv = ~__hip_atomic_load(&vis.bits[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
+          if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
+        }
+        const u64 mk = __ballot(unv != 0u);
+        if (!mk) {
+          pos = (wbase + 64u) << 5;
+          continue;
+        }
+        const int l0 = __ffsll((long long)mk) - 1;
+        const u32 w0 = (u32)__builtin_amdgcn_readlane((int)unv, l0);
+        const u32 slot = ((wbase + (u32)l0) << 5) + (u32)__builtin_ctz(w0);
+        pos = slot + 1;
+        if (g.incremental && !g.has_vec[slot]) continue; // prefix_iter over Item keys: existing items
+        const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
+        if (ln == 0) eps[0] = slot;
+        WSYNC();
+        walk_one_layer<LPR, NCH>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter);
+        if (total + s.res_len > (int)a.rcap) {
+          s.err = 1;
+          break;
+        }
+        for (int e = ln; e < s.res_len; e += 64) { // neighbours.extend(more_nns)
+          u64 k = s.res[e];
+          a.cand[(size_t)m * a.rcap + total + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+        }
+        total += s.res_len;
+        if (total >= (int)a.knn_ef) break; // :792-794
+      }
+      // drain_asc(): sort everything that was collected
+      __threadfence_block();
+      WSYNC();
+      for (int e = ln; e < total; e += 64) s.res[e] = a.cand[(size_t)m * a.rcap + e];
+      WSYNC();
+      for (int e = ln; e < total; e += 64) {
+        const u64 mine = s.res[e];
+        int rk = 0;
+        for (int k2 = 0; k2 < total; k2++) rk += s.res[k2] < mine ? 1 : 0;
+        a.cand[(size_t)m * a.rcap + rk] = mine;
+      }
+      WSYNC();
+    }
+    if (ln == 0) a.cand_n[m] = (u32)total;
     if (vis.log_over) log_over_cnt++;
     visited_clear(vis);
   }

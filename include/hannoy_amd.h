@@ -139,6 +139,14 @@ int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, co
 
 /* ---- stepwise build (what hny_build loops over; used by the multi-GPU driver) ---- */
 int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out);
+/* stepwise form of hny_build_incremental: after the batches call hny_builder_fill_gaps once, then
+ * hny_builder_finish.  With nothing to insert or delete this simply loads a stored graph into HBM
+ * (e.g. for hny_builder_search_knn). */
+int hny_builder_create_incremental(const hny_build_opts *opts, const hny_items *items,
+                                   const uint32_t *to_insert, uint64_t n_insert,
+                                   const uint32_t *to_delete, uint64_t n_delete,
+                                   const hny_prev_graph *prev, hny_builder **out);
+int hny_builder_fill_gaps(hny_builder *b); /* fill_gaps_from_deleted, hnsw.rs:187, 334-415 */
 int hny_builder_reset(hny_builder *b); /* empty graph again, vectors stay resident in HBM */
 int hny_builder_next_batch(hny_builder *b, hny_batch *out);
 /* search + prune (walk_layer hnsw.rs:460-518, robust_prune :565-597) for members [lo, hi) of the

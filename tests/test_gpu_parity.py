@@ -228,3 +228,29 @@ def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac,
         alive_set = set(vecs.keys())
         assert all(set(nb) <= alive_set for nb in d.values())
         assert {i for (i, l) in d if l == 0} == alive_set
+
+
+def test_visited_log_overflow_fallback(orc, hny, monkeypatch):
+    """With a tiny visited log every walk overflows it and clears its whole bitset instead: same graph."""
+    monkeypatch.setenv("HNY_VISITED_LOG", "1024")
+    monkeypatch.setenv("HNY_WALK_SLOTS", "64")
+    rng = np.random.default_rng(3)
+    n, dim = 6000, 32
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, 1, vecs, draw_levels(n, 16, seed=3))
+    o = orc.build(ds, M=16, M0=32, ef=200, order=orc.ORDER_WAVE, batch_frac=0.25, batch_max=512)
+    g = hny.build(items, M=16, M0=32, ef_construction=200, batch_frac=0.25, batch_max=512)
+    _same_graph(g, o)
+    assert g.n_evals_walk / n > 1024  # the log (1024 entries) must have overflowed
+
+
+def test_wave_prune_variant_matches(orc, hny, monkeypatch):
+    """HNY_PRUNE_WAVE=1 (single-wave prune without LDS staging) builds the same graph."""
+    monkeypatch.setenv("HNY_PRUNE_WAVE", "1")
+    rng = np.random.default_rng(4)
+    n, dim = 3000, 64
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, 8, seed=4))
+    o = orc.build(ds, M=8, M0=16, ef=64, order=orc.ORDER_WAVE, batch_frac=0.25, batch_max=256)
+    g = hny.build(items, M=8, M0=16, ef_construction=64, batch_frac=0.25, batch_max=256)
+    _same_graph(g, o)
