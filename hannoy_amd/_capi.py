@@ -260,9 +260,12 @@ class Graph:
         self._gp, self._opts, self._items = gp, opts, items
 
     def __del__(self):
-        if getattr(self, "_gp", None) is not None:
-            load_library().hny_graph_free(self._gp)
-            self._gp = None
+        try:
+            if getattr(self, "_gp", None) is not None:
+                load_library().hny_graph_free(self._gp)
+                self._gp = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def as_dict(self):
         return {(int(self.rec_item[r]), int(self.rec_layer[r])):

@@ -235,9 +235,12 @@ class Graph:
         self.n_links_added = L.orc_graph_links_added(handle)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_graph_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_graph_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def as_dict(self):
         """{(item, layer): [neighbour ids]}"""
