@@ -307,14 +307,14 @@ int pick_shape(int metric, uint32_t dim, LaunchShape &s, uint32_t &n16) {
   if (l < 8) l = 8;
   if (l > 64) l = 64;
   uint32_t c = (n16 + l - 1) / l;
-  static const uint32_t set[] = {1, 2, 3, 4, 6, 8};
+  static const uint32_t set[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (uint32_t v : set)
     if (c <= v) {
       s.lpr = (int)l;
       s.nch = (int)v;
       return HNY_OK;
     }
-  return fail(HNY_ERR_UNSUPPORTED, "dim %u needs more than 8 chunks per lane (max f32 dim 2048)", dim);
+  return fail(HNY_ERR_UNSUPPORTED, "dim %u needs more than 16 chunks per lane (max f32 dim 4096)", dim);
 }
 
 int mclass_of(int metric) {
@@ -704,7 +704,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     int sl = (int)((u32)std::max(0, env_int("HNY_STAGE_BYTES", 24576)) / (n16 * 16u));
     if (sl > HNY_MAX_CAP) sl = HNY_MAX_CAP;
     b->stage_rows = sl / rpg * rpg;
-    b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0;
+    b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0 || b->shape.nch > 8;
   }
 
   // ---- device memory ----

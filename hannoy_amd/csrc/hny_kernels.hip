@@ -214,7 +214,7 @@ __device__ __forceinline__ float finalize_bin(const GraphDev &g, u32 pop, float 
 template <int NCH>
 struct RowsInFlight {
   // 16-byte loads in flight per lane ~ 12..16
-  static constexpr int U = NCH >= 6 ? 2 : (NCH >= 3 ? 4 : (NCH == 2 ? 6 : 8));
+  static constexpr int U = NCH >= 12 ? 1 : (NCH >= 6 ? 2 : (NCH >= 3 ? 4 : (NCH == 2 ? 6 : 8)));
 };
 
 // distances from the query (registers) to rows ids[0..n) (LDS) -> out[0..n) (LDS).
@@ -246,7 +246,7 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
       }
     }
     // reduce the U load groups 4 (or 2) at a time with folded butterflies
-    constexpr int F = (U % 4 == 0) ? 4 : 2;
+    constexpr int F = (U % 4 == 0) ? 4 : (U % 2 == 0 ? 2 : 1);
 #pragma unroll
     for (int u0 = 0; u0 < U; u0 += F) {
       if (k0 + u0 * RPG < n) { // wave-uniform
@@ -258,6 +258,9 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
             pc = fold4<LPR, u32>(partial_bin<NCH>(q, r[u0]), partial_bin<NCH>(q, r[u0 + 1]),
                                  partial_bin<NCH>(q, r[u0 + 2]), partial_bin<NCH>(q, r[u0 + 3]));
             j = fold4_row<LPR>();
+          } else if constexpr (F == 1) {
+            pc = butterfly_u32<LPR>(partial_bin<NCH>(q, r[u0]));
+            j = 0;
           } else {
             pc = fold2<LPR, u32>(partial_bin<NCH>(q, r[u0]), partial_bin<NCH>(q, r[u0 + 1]));
             j = fold2_row<LPR>();
@@ -274,6 +277,9 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
                                    partial_f32<NCH>(g.mclass, q, r[u0 + 2]),
                                    partial_f32<NCH>(g.mclass, q, r[u0 + 3]));
             j = fold4_row<LPR>();
+          } else if constexpr (F == 1) {
+            pa = butterfly_f32<LPR>(partial_f32<NCH>(g.mclass, q, r[u0]));
+            j = 0;
           } else {
             pa = fold2<LPR, float>(partial_f32<NCH>(g.mclass, q, r[u0]),
                                    partial_f32<NCH>(g.mclass, q, r[u0 + 1]));
@@ -285,7 +291,7 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
           d = finalize_f32(g, pa, qn, rnj);
         }
         int ri = k0 + (u0 + j) * RPG + sub;
-        if ((t & (LPR / F - 1)) == 0 && ri < n) out[ri] = d;
+        if ((t & (F == 1 ? LPR - 1 : LPR / F - 1)) == 0 && ri < n) out[ri] = d;
       }
     }
   }
@@ -1484,6 +1490,8 @@ hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
   HNY_CASE(64, 4)
   HNY_CASE(64, 6)
   HNY_CASE(64, 8)
+  HNY_CASE(64, 12)
+  HNY_CASE(64, 16)
 #undef HNY_CASE
   return hipErrorInvalidValue;
 }
@@ -1507,17 +1515,25 @@ struct PruneLauncher {
 template <int L, int C>
 struct PruneWgLauncher {
   static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int grid, hipStream_t st) {
-    size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL);
-    hipLaunchKernelGGL((k_prune_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
-    return hipGetLastError();
+    if constexpr (C > 8) {
+      return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
+    } else {
+      size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL);
+      hipLaunchKernelGGL((k_prune_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
+      return hipGetLastError();
+    }
   }
 };
 template <int L, int C>
 struct ApplyWgLauncher {
   static hipError_t run(const GraphDev &g, const ApplyArgs &a, int SL, int grid, hipStream_t st) {
-    size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL);
-    hipLaunchKernelGGL((k_apply_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
-    return hipGetLastError();
+    if constexpr (C > 8) {
+      return hipErrorInvalidValue;
+    } else {
+      size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL);
+      hipLaunchKernelGGL((k_apply_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
+      return hipGetLastError();
+    }
   }
 };
 template <int L, int C>

@@ -245,10 +245,10 @@ inline uint32_t wave_lpr(uint32_t dim) {
   return l;
 }
 enum { WOP_DOT = 0, WOP_EUCLID = 1, WOP_MANHATTAN = 2 };
-/* chunks per lane, rounded up to the kernel's template set {1,2,3,4,6,8} */
+/* chunks per lane, rounded up to the kernel's template set {1,2,3,4,6,8,12,16} */
 inline uint32_t wave_nch(uint32_t dim4, uint32_t lpr) {
   uint32_t n = (dim4 + lpr - 1) / lpr;
-  static const uint32_t set[] = {1, 2, 3, 4, 6, 8};
+  static const uint32_t set[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (uint32_t s : set)
     if (n <= s) return s;
   return n;

@@ -41,7 +41,8 @@ def test_kat1_on_gpu(kat, orc, hny):
 
 
 @pytest.mark.parametrize("metric,dim", [(0, 768), (1, 768), (2, 96), (0, 128), (1, 3), (0, 20),
-                                        (3, 1024), (4, 256), (5, 100), (6, 64), (0, 1536)])
+                                        (3, 1024), (4, 256), (5, 100), (6, 64), (0, 1536), (0, 3072), (1, 4096),
+                                        (2, 2500), (3, 4096)])
 def test_pair_distances_bit_exact_wave_order(orc, hny, metric, dim):
     rng = np.random.default_rng(100 + metric * 7 + dim)
     n = 300
@@ -80,6 +81,8 @@ CASES = [
     (5, 1000, 100, 6, 6, 16, 0.05, 64),
     (6, 1000, 64, 6, 6, 16, 0.05, 64),
     (1, 2500, 100, 32, 64, 200, 0.05, 256),
+    (0, 800, 3072, 8, 16, 32, 0.1, 64),
+    (1, 600, 2100, 6, 12, 24, 0.1, 64),
 ]
 
 
