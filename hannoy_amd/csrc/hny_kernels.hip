@@ -645,8 +645,11 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
 #ifndef HNY_WALK_WPE
 #define HNY_WALK_WPE 4
 #endif
+#ifndef HNY_WALK_WPE_SMALL
+#define HNY_WALK_WPE_SMALL 4
+#endif
 template <int LPR, int NCH>
-__global__ __launch_bounds__(64, HNY_WALK_WPE) void k_walk(GraphDev g, WalkArgs a) {
+__global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g, WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
