@@ -11,10 +11,11 @@ import math
 
 class Driver:
     def __init__(self, builder, torch, dist, rank=0, world=1, device=None, min_shard_batch=None,
-                 host_staged=False):
+                 host_staged=False, force_collective=False):
         self.b, self.torch, self.dist = builder, torch, dist
         # host_staged: exchange through host memory (gloo); default is device buffers over RCCL
         self.host_staged = host_staged
+        self.force_collective = force_collective  # tests: run the exchange even with one rank
         self.rank, self.world, self.device = rank, world, device
         self.min_shard = 64 * world if min_shard_batch is None else min_shard_batch
         self._buf = None
@@ -34,7 +35,7 @@ class Driver:
 
     def run(self):
         b = self.b
-        if self.world == 1 or self.dist is None:
+        if self.dist is None or (self.world == 1 and not self.force_collective):
             return b.run()
         n = 0
         while True:

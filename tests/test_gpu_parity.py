@@ -323,3 +323,36 @@ def test_full_size_c2_properties(orc, hny):
     hit = sum(len(set(ids[i, :cnt[i]].tolist()) & set(truth[i].tolist())) for i in range(nq))
     assert hit / (10 * nq) >= 0.90
     assert np.all(np.diff(dists, axis=1) >= 0)  # drain_asc
+
+
+def test_rccl_exchange_path_single_rank(orc, hny):
+    """The multi-GPU driver's exchange on the real thing: `nccl` (= RCCL) process group with one rank,
+    all_gather_into_tensor on the device selection buffer handed to the C ABI, then apply from it.
+    The graph must equal the plain single-GPU build."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from hannoy_amd.multigpu import Driver
+    rng = np.random.default_rng(9)
+    n, dim = 6000, 96
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, 16, seed=9))
+    ref = hny.build(items, M=16, M0=32, ef_construction=64, batch_frac=0.25, batch_max=1024)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        with hny.Builder(items, M=16, M0=32, ef_construction=64, batch_frac=0.25, batch_max=1024) as b:
+            drv = Driver(b, torch, dist, 0, 1, dev, min_shard_batch=64, force_collective=True)
+            drv.run()
+            g = b.finish()
+        assert drv.n_collectives > 0
+    finally:
+        dist.destroy_process_group()
+    _same_graph(g, ref)
