@@ -25,7 +25,7 @@ EXPORTED = [
     "hny_builder_finish", "hny_builder_destroy", "hny_builder_set_profiling", "hny_batch_size", "hny_builder_distances",
     "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
     "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels", "hny_build_incremental",
-    "hny_builder_create_incremental", "hny_builder_fill_gaps",
+    "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
 ]
 
 
@@ -151,6 +151,8 @@ def load_library():
     L.hny_header_bytes.argtypes = [C.c_int32]
     L.hny_encode_vectors.restype = C.c_int
     L.hny_encode_vectors.argtypes = [C.c_int32, C.c_uint32, C.c_uint64, vp, vp, vp]
+    L.hny_encode_vectors_gpu.restype = C.c_int
+    L.hny_encode_vectors_gpu.argtypes = [C.c_int32, C.c_uint32, C.c_uint64, vp, vp, vp, C.c_int32]
     L.hny_encode_kv.restype = C.c_int
     L.hny_encode_kv.argtypes = [C.POINTER(GraphStruct), C.POINTER(BuildOpts), C.POINTER(Items),
                                 C.c_uint16, C.c_int, KV_SINK, vp]
@@ -184,13 +186,18 @@ def header_bytes(metric):
     return load_library().hny_header_bytes(metric)
 
 
-def encode_vectors(metric, vecs):
-    """UnalignedVectorCodec::from_slice + Distance::new_header for a [n, dim] f32 matrix."""
+def encode_vectors(metric, vecs, gpu=False, device=-1):
+    """UnalignedVectorCodec::from_slice + Distance::new_header for a [n, dim] f32 matrix
+    (gpu=True: hny_encode_vectors_gpu, byte-identical)."""
     vecs = np.ascontiguousarray(vecs, dtype=np.float32)
     n, dim = vecs.shape
     codes = np.zeros((n, vector_bytes(metric, dim)), np.uint8)
     headers = np.zeros((n, header_bytes(metric)), np.uint8)
-    _check(load_library().hny_encode_vectors(metric, dim, n, _p(vecs), _p(codes), _p(headers)))
+    if gpu:
+        _check(load_library().hny_encode_vectors_gpu(metric, dim, n, _p(vecs), _p(codes), _p(headers),
+                                                     device))
+    else:
+        _check(load_library().hny_encode_vectors(metric, dim, n, _p(vecs), _p(codes), _p(headers)))
     return codes, headers
 
 

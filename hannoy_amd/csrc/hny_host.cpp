@@ -463,6 +463,51 @@ int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *ve
   return HNY_OK;
 }
 
+// the same on the device: codes through k_quantize, Cosine norms through k_norms_x86 (bit-identical
+// to the host path above), streamed in chunks so that any n fits
+int hny_encode_vectors_gpu(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
+                           void *out_codes, void *out_headers, int32_t device) {
+  if (!vectors || !out_codes || !out_headers || metric < 0 || metric > HNY_BQ_MANHATTAN || dim == 0)
+    return fail(HNY_ERR_INVALID_ARG, "hny_encode_vectors_gpu: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(HNY_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  const size_t vb = vec_bytes(metric, dim), hb = hdr_bytes(metric);
+  const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)dim * 4));
+  DevBuf<float> dv, dn;
+  DevBuf<u64> dc;
+  HIP_TRY(dv.alloc(std::min(chunk, std::max<uint64_t>(n, 1)) * dim));
+  if (metric == HNY_COSINE) HIP_TRY(dn.alloc(std::min(chunk, std::max<uint64_t>(n, 1))));
+  if (is_binary(metric)) HIP_TRY(dc.alloc(std::min(chunk, std::max<uint64_t>(n, 1)) * (vb / 8)));
+  std::vector<float> norms;
+  for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
+    const uint64_t cnt = std::min(chunk, n - i0);
+    unsigned char *codes = (unsigned char *)out_codes + i0 * vb;
+    unsigned char *hdrs = (unsigned char *)out_headers + i0 * hb;
+    memset(hdrs, 0, cnt * hb); // bias 0.0 (euclidean.rs:38-40 ...), idx 0 (hamming.rs:40-42)
+    if (metric == HNY_COSINE || is_binary(metric))
+      HIP_TRY(hipMemcpy(dv.p, vectors + i0 * dim, cnt * dim * 4, hipMemcpyHostToDevice));
+    if (!is_binary(metric)) {
+      memcpy(codes, vectors + i0 * dim, cnt * vb); // f32.rs:9-55
+      if (metric == HNY_COSINE) {
+        HIP_TRY(hnyk_norms_x86(dv.p, dim, cnt, dn.p, nullptr));
+        norms.resize(cnt);
+        HIP_TRY(hipMemcpy(norms.data(), dn.p, cnt * 4, hipMemcpyDeviceToHost));
+        memcpy(hdrs, norms.data(), cnt * 4);
+      }
+    } else {
+      HIP_TRY(hnyk_quantize(dv.p, dim, cnt, metric == HNY_HAMMING, dc.p, nullptr));
+      HIP_TRY(hipMemcpy(codes, dc.p, cnt * vb, hipMemcpyDeviceToHost));
+      if (metric == HNY_BQ_COSINE) { // sqrt(dot_bq(v,v)) = sqrt(padded dims)
+        float h = sqrtf((float)(int32_t)(vb * 8));
+        for (uint64_t i = 0; i < cnt; i++) memcpy(hdrs + i * 4, &h, 4);
+      }
+    }
+  }
+  return HNY_OK;
+}
+
 void hny_builder_destroy(hny_builder *b) {
   if (!b) return;
   if (b->stream) {

@@ -148,3 +148,5 @@ hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const 
                           LaunchShape s, hipStream_t st);
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st);
 size_t hnyk_walk_lds_bytes(u32 rcap);
+hipError_t hnyk_norms_x86(const float *v, u32 dim, u64 n, float *out, hipStream_t st);
+hipError_t hnyk_quantize(const float *v, u32 dim, u64 n, int binary_codec, u64 *out, hipStream_t st);

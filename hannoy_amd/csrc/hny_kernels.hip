@@ -1474,6 +1474,83 @@ __global__ __launch_bounds__(64) void k_finalize_lists(u32 *ids, u32 *cnt_out, u
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// add_item side (writer.rs:462-480): Distance::new_header and the bit codecs, on the device.
+// Cosine norm = sqrt(dot(v, v)) in the REFERENCE's x86 summation order, so that the stored headers
+// are bit-identical to what hannoy itself writes: 32 fma partials + hsum tree for dim >= 32
+// (simple_avx.rs:8-13,69-110), 16 unfused partials for 16 <= dim < 32 (simple_sse.rs:10-14,64-110),
+// scalar below (simple.rs:81-83).  One half-wave (32 lanes = the 32 partials) per vector.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_norms_x86(const float *v, u32 dim, u64 n, float *out) {
+  const int ln = threadIdx.x, j = ln & 31, half = ln >> 5;
+  for (u64 vi = (u64)blockIdx.x * 2 + half; vi < n; vi += (u64)gridDim.x * 2) {
+    const float *x = v + vi * dim;
+    float r;
+    if (dim >= 32) {
+      const u32 m = dim - dim % 32;
+      float acc = 0.f;
+      for (u32 i = 0; i < m; i += 32) acc = __builtin_fmaf(x[i + j], x[i + j], acc);
+      acc = acc + __shfl_xor(acc, 4, 64); // hsum256: lane k + lane k+4
+      acc = acc + __shfl_xor(acc, 2, 64); //          k + k+2
+      acc = acc + __shfl_xor(acc, 1, 64); //          0 + 1
+      const int b = half * 32;
+      const float h1 = __shfl(acc, b, 64), h2 = __shfl(acc, b + 8, 64), h3 = __shfl(acc, b + 16, 64),
+                  h4 = __shfl(acc, b + 24, 64);
+      r = ((h1 + h2) + h3) + h4;
+      for (u32 i = m; i < dim; i++) { // scalar tail, unfused
+        float p = x[i] * x[i];
+        r = r + p;
+      }
+    } else if (dim >= 16) {
+      const u32 m = dim - dim % 16;
+      float acc = 0.f;
+      if (j < 16)
+        for (u32 i = 0; i < m; i += 16) {
+          float p = x[i + j] * x[i + j];
+          acc = p + acc;
+        }
+      acc = acc + __shfl_xor(acc, 2, 64); // hsum128: k + k+2
+      acc = acc + __shfl_xor(acc, 1, 64); //          0 + 1
+      const int b = half * 32;
+      const float h1 = __shfl(acc, b, 64), h2 = __shfl(acc, b + 4, 64), h3 = __shfl(acc, b + 8, 64),
+                  h4 = __shfl(acc, b + 12, 64);
+      r = ((h1 + h2) + h3) + h4;
+      for (u32 i = m; i < dim; i++) {
+        float p = x[i] * x[i];
+        r = r + p;
+      }
+    } else {
+      r = 0.f;
+      for (u32 i = 0; i < dim; i++) {
+        float p = x[i] * x[i];
+        r = r + p;
+      }
+    }
+    if (j == 0) out[vi] = __builtin_sqrtf(r);
+  }
+}
+
+// Binary::from_slice (binary.rs:80-94: bit = 0 < bits < 0x8000_0000) / BinaryQuantized::from_slice
+// (binary_quantized.rs:80-91: bit = is_sign_positive); dim i -> bit i%64 of u64 word i/64, zero
+// padded.  One wave per 64-dim word: the ballot IS the word.
+__global__ __launch_bounds__(64) void k_quantize(const float *v, u32 dim, u64 n, int binary_codec,
+                                                 u64 *out) {
+  const u32 words = (dim + 63) / 64;
+  const u64 total = n * words;
+  const int ln = threadIdx.x;
+  for (u64 w = blockIdx.x; w < total; w += gridDim.x) {
+    const u64 vi = w / words;
+    const u32 d = (u32)(w % words) * 64 + (u32)ln;
+    bool one = false;
+    if (d < dim) {
+      const u32 bits = __float_as_uint(v[vi * dim + d]);
+      one = binary_codec ? (bits < 0x80000000u && bits > 0u) : (bits >> 31) == 0u;
+    }
+    const u64 word = __ballot(one);
+    if (ln == 0) out[w] = word;
+  }
+}
+
 __global__ void k_fill_u32(u32 *p, u32 v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1614,6 +1691,20 @@ hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hip
   if (!n_lists) return hipSuccess;
   unsigned grid = n_lists < 65536u * 4u ? n_lists : 65536u * 4u;
   hipLaunchKernelGGL(k_finalize_lists, dim3(grid), dim3(64), 0, st, ids, cnt_out, n_lists, cap);
+  return hipGetLastError();
+}
+hipError_t hnyk_norms_x86(const float *v, u32 dim, u64 n, float *out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  u64 blocks = (n + 1) / 2;
+  if (blocks > 262144) blocks = 262144;
+  hipLaunchKernelGGL(k_norms_x86, dim3((unsigned)blocks), dim3(64), 0, st, v, dim, n, out);
+  return hipGetLastError();
+}
+hipError_t hnyk_quantize(const float *v, u32 dim, u64 n, int binary_codec, u64 *out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  u64 blocks = n * ((dim + 63) / 64);
+  if (blocks > 1048576) blocks = 1048576;
+  hipLaunchKernelGGL(k_quantize, dim3((unsigned)blocks), dim3(64), 0, st, v, dim, n, binary_codec, out);
   return hipGetLastError();
 }
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st) {

@@ -182,6 +182,10 @@ size_t hny_vector_bytes(int32_t metric, uint32_t dim);
 size_t hny_header_bytes(int32_t metric);
 int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
                        void *out_codes, void *out_headers);
+/* the same on the GPU (bulk ingest): bit codecs by ballot, Cosine norms in the reference's x86
+ * summation order (simple_avx.rs / simple_sse.rs / scalar) — byte-identical to the host path */
+int hny_encode_vectors_gpu(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
+                           void *out_codes, void *out_headers, int32_t device);
 
 /* ---- on-disk records (key.rs:54-82, node.rs:130-174, metadata.rs:22-73, version.rs:33-60) ---- */
 typedef int (*hny_kv_sink)(void *ctx, const uint8_t *key, size_t key_len, const uint8_t *val,
