@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-recall", action="store_true")
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--x86-order", action="store_true",
+                   help="strict mode: f32 distances in the reference's x86 summation order")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo: test mode, ranks may share one GPU, exchange staged through the host")
     return p.parse_args()
@@ -132,7 +134,8 @@ def main():
     bytes_per_eval = row_bytes + items.headers.shape[1]  # row + header
 
     builder = H.Builder(items, M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed,
-                        batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank)
+                        batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank,
+                        x86_order=a.x86_order)
     builder.set_profiling(True)
     driver = multigpu.Driver(builder, torch, dist if world > 1 else None, rank, world, dev,
                              host_staged=(a.backend == "gloo"))
@@ -181,7 +184,7 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_tuned.json")
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
-                  and world == 1)
+                  and world == 1 and not a.x86_order)
     if roof and default_c2 and os.path.exists(pmc_file):
         with open(pmc_file) as f:
             pk = json.load(f).get("k_walk")
@@ -202,7 +205,8 @@ def main():
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
                    "batch_frac": builder.opts.batch_frac or 0.25,
                    "batch_max": builder.opts.batch_max or 32768,
-                   "parallelism": f"item-sharded search x{world}, replicated graph"},
+                   "parallelism": f"item-sharded search x{world}, replicated graph",
+                   "distance_order": "x86 (strict)" if a.x86_order else "wave"},
         "roofline": roof,
         "build": {"n_batches": int(graph.n_batches), "n_distance_evals": int(graph.n_distance_evals),
                   "evals_walk": int(graph.n_evals_walk), "evals_prune": int(graph.n_evals_prune),

@@ -50,7 +50,8 @@ class BuildOpts(C.Structure):
                 ("ef_construction", C.c_uint32), ("alpha", C.c_float), ("seed", C.c_uint64),
                 ("cancel", CANCEL_FN), ("cancel_ctx", C.c_void_p),
                 ("progress", PROGRESS_FN), ("progress_ctx", C.c_void_p),
-                ("batch_frac", C.c_double), ("batch_max", C.c_uint32), ("device", C.c_int32)]
+                ("batch_frac", C.c_double), ("batch_max", C.c_uint32), ("device", C.c_int32),
+                ("x86_order", C.c_int32)]
 
 
 class Items(C.Structure):
@@ -227,11 +228,12 @@ class ItemSet:
 
 
 def make_opts(metric, dim, M=16, M0=32, ef_construction=100, alpha=1.0, seed=42, batch_frac=0.0,
-              batch_max=0, device=-1, cancel=None, progress=None):
+              batch_max=0, device=-1, cancel=None, progress=None, x86_order=False):
     o = BuildOpts()
     o.metric, o.dim, o.M, o.M0 = metric, dim, M, M0
     o.ef_construction, o.alpha, o.seed = ef_construction, alpha, seed
     o.batch_frac, o.batch_max, o.device = batch_frac, batch_max, device
+    o.x86_order = int(bool(x86_order))
     keep = []
     if cancel is not None:
         fn = CANCEL_FN(lambda _ctx: 1 if cancel() else 0)

@@ -749,7 +749,9 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     int sl = (int)((u32)std::max(0, env_int("HNY_STAGE_BYTES", 24576)) / (n16 * 16u));
     if (sl > HNY_MAX_CAP) sl = HNY_MAX_CAP;
     b->stage_rows = sl / rpg * rpg;
-    b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0 || b->shape.nch > 8;
+    // the workgroup prune kernels carry their own wave-order arithmetic: strict mode and very long
+    // rows use the single-wave kernels, which all go through dist_rows
+    b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0 || b->shape.nch > 8 || o.x86_order;
   }
 
   // ---- device memory ----
@@ -767,6 +769,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   g.n_upper = b->n_upper;
   g.alpha = o.alpha;
   g.incremental = inc ? 1 : 0;
+  g.dim = o.dim;
+  g.x86_order = o.x86_order ? 1 : 0;
   const size_t nn = std::max<uint32_t>(n, 1);
   const size_t no = std::max<size_t>(b->order.size(), 1);
   HIP_TRY(b->d_rows.alloc(nn * g.row_stride));

@@ -54,6 +54,8 @@ struct GraphDev {
   float *up_dist;
   u32 *up_cnt;   // [n_upper][up_layers]
   u64 *stats;    // [ST_COUNT]
+  u32 dim;       // user dimensions (f32 metrics)
+  int x86_order; // 1: f32 distances in the reference's x86 summation order (strict mode)
   u32 up_layers; // upper layers that have storage (== max(max_level,1) for a fresh build)
   // incremental builds: the previous graph as stored in LMDB (read-only) + which items still exist
   int incremental;

@@ -217,11 +217,122 @@ struct RowsInFlight {
   static constexpr int U = NCH >= 12 ? 1 : (NCH >= 6 ? 2 : (NCH >= 3 ? 4 : (NCH == 2 ? 6 : 8)));
 };
 
+// Strict mode: the f32 distances exactly as the reference computes them on an x86_64 host with
+// AVX+FMA (dispatch simple.rs:19-47,53-79): dim >= 32 -> 32 fma partials, element i -> partial
+// i % 32, hsum256 per 8 partials then ((h1+h2)+h3)+h4, unfused scalar tail (simple_avx.rs);
+// 16 <= dim < 32 -> 16 unfused partials (simple_sse.rs); below -> scalar left to right
+// (simple.rs:49-51,81-83); Manhattan is always the scalar iterator sum (manhattan.rs:41-43).
+// One half-wave per row (lane j = partial j), dword loads: slower than the wave order, meant for
+// parity runs (x86_order = 1).
+__device__ __forceinline__ float x86_row_distance(const GraphDev &g, const float *a, const float *b,
+                                                  int j, int base) {
+  const u32 dim = g.dim;
+  float r;
+  if (g.mclass == MC_L1) {
+    r = 0.f;
+    for (u32 i = 0; i < dim; i++) r = r + __builtin_fabsf(a[i] - b[i]);
+    return r;
+  }
+  const bool dot = g.mclass == MC_DOT;
+  if (dim >= 32) {
+    const u32 m = dim - dim % 32;
+    float acc = 0.f;
+    for (u32 i = 0; i < m; i += 32) {
+      const float x = a[i + j], y = b[i + j];
+      if (dot) {
+        acc = __builtin_fmaf(x, y, acc);
+      } else {
+        const float d = x - y;
+        acc = __builtin_fmaf(d, d, acc);
+      }
+    }
+    acc = acc + __shfl_xor(acc, 4, 64);
+    acc = acc + __shfl_xor(acc, 2, 64);
+    acc = acc + __shfl_xor(acc, 1, 64);
+    const float h1 = __shfl(acc, base, 64), h2 = __shfl(acc, base + 8, 64),
+                h3 = __shfl(acc, base + 16, 64), h4 = __shfl(acc, base + 24, 64);
+    r = ((h1 + h2) + h3) + h4;
+    for (u32 i = m; i < dim; i++) {
+      float p;
+      if (dot) {
+        p = a[i] * b[i];
+      } else {
+        const float d = a[i] - b[i];
+        p = d * d;
+      }
+      r = r + p;
+    }
+  } else if (dim >= 16) {
+    const u32 m = dim - dim % 16;
+    float acc = 0.f;
+    if (j < 16)
+      for (u32 i = 0; i < m; i += 16) {
+        const float x = a[i + j], y = b[i + j];
+        float p;
+        if (dot) {
+          p = x * y;
+        } else {
+          const float d = x - y;
+          p = d * d;
+        }
+        acc = p + acc;
+      }
+    acc = acc + __shfl_xor(acc, 2, 64);
+    acc = acc + __shfl_xor(acc, 1, 64);
+    const float h1 = __shfl(acc, base, 64), h2 = __shfl(acc, base + 4, 64),
+                h3 = __shfl(acc, base + 8, 64), h4 = __shfl(acc, base + 12, 64);
+    r = ((h1 + h2) + h3) + h4;
+    for (u32 i = m; i < dim; i++) {
+      float p;
+      if (dot) {
+        p = a[i] * b[i];
+      } else {
+        const float d = a[i] - b[i];
+        p = d * d;
+      }
+      r = r + p;
+    }
+  } else {
+    r = 0.f;
+    for (u32 i = 0; i < dim; i++) {
+      float p;
+      if (dot) {
+        p = a[i] * b[i];
+      } else {
+        const float d = a[i] - b[i];
+        p = d * d;
+      }
+      r = r + p;
+    }
+  }
+  return r;
+}
+
+__device__ void dist_rows_x86(const GraphDev &g, const unsigned char *qrow, float qn, const u32 *ids,
+                              int n, float *out) {
+  const int ln = threadIdx.x & 63, j = ln & 31, half = ln >> 5;
+  for (int k0 = 0; k0 < n; k0 += 2) {
+    int ri = k0 + half;
+    const bool on = ri < n;
+    if (!on) ri = n - 1;
+    const u32 rid = ids[ri];
+    const float *b = reinterpret_cast<const float *>(g.rows + (size_t)rid * g.row_stride);
+    const float acc = x86_row_distance(g, reinterpret_cast<const float *>(qrow), b, j, half * 32);
+    const float d = finalize_f32(g, acc, qn, g.norms ? g.norms[rid] : 0.f);
+    if (j == 0 && on) out[ri] = d;
+  }
+}
+
 // distances from the query (registers) to rows ids[0..n) (LDS) -> out[0..n) (LDS).
 // D::distance at hnsw.rs:476,503,584.
 template <int LPR, int NCH>
 __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[NCH], float qn,
-                                          const u32 *ids, int n, float *out) {
+                                          const u32 *ids, int n, float *out,
+                                          const unsigned char *qrow) {
+  if (g.x86_order && g.mclass != MC_BIN) { // strict mode (wave-uniform)
+    dist_rows_x86(g, qrow, qn, ids, n, out);
+    return;
+  }
   constexpr int RPG = 64 / LPR;               // rows per wave-wide load instruction
   constexpr int U = RowsInFlight<NCH>::U;     // load groups in flight
   constexpr int RPI = RPG * U;
@@ -478,7 +589,8 @@ __device__ __forceinline__ void visited_log(Visited &v, u32 id, bool isnew, u64 
 template <int LPR, int NCH>
 __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
-                               u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter) {
+                               u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
+                               const unsigned char *qrow) {
   const int ln = threadIdx.x;
   s.res_len = 0;
   s.pool_len = 0;
@@ -493,7 +605,7 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
     if (ln < n_eps) nb_ids[ln] = id;
     WSYNC();
-    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_eps, nb_d);
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_eps, nb_d, qrow);
     evals += (u64)n_eps;
     WSYNC();
     for (int r = 0; r < n_eps; r++) {
@@ -620,7 +732,7 @@ __device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float 
       const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
       if (isnew) nb_ids[rank] = id;
       WSYNC();
-      dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d); // :503
+      dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow); // :503
       evals += (u64)n_new;
       WSYNC();
       const float myd = ln < n_new ? nb_d[ln] : 0.f;
@@ -715,7 +827,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       walk_one_layer<LPR, NCH>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
-                               nb_d, evals, err_iter);
+                               nb_d, evals, err_iter, qrow);
       if (last) break;
       // :305-306 eps = [closest]
       if (ln == 0) eps[0] = (u32)(s.res[0] >> 1) & 0x7FFFFFFFu;
@@ -762,7 +874,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter);
+        walk_one_layer<LPR, NCH>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
@@ -821,7 +933,7 @@ __device__ int wave_prune(const GraphDev &g, const u64 *list, int n, int cap, u6
     bool viol = false;
     for (int k0 = 0; k0 < s_len && !viol; k0 += RPI) {
       int cnt = s_len - k0 < RPI ? s_len - k0 : RPI;
-      dist_rows<LPR, NCH>(g, c, cn, s_ids + k0, cnt, tmp_d);
+      dist_rows<LPR, NCH>(g, c, cn, s_ids + k0, cnt, tmp_d, g.rows + (size_t)cid * g.row_stride);
       evals += (u64)cnt;
       WSYNC();
       bool v = false;
@@ -1393,7 +1505,7 @@ __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u
     if (ln < cnt) keys[ln] = ((u64)fbits(od) << 32) | oi;
     for (int base = 0; base < nb; base += 64) {
       const int c = nb - base < 64 ? nb - base : 64;
-      dist_rows<LPR, NCH>(g, q, qn, bm + base, c, tmp_d);
+      dist_rows<LPR, NCH>(g, q, qn, bm + base, c, tmp_d, g.rows + (size_t)slot * g.row_stride);
       evals += (u64)c;
       WSYNC();
       if (ln < c) keys[cnt + base + ln] = ((u64)fbits(tmp_d[ln]) << 32) | bm[base + ln];
@@ -1439,7 +1551,7 @@ __global__ __launch_bounds__(64) void k_pair_distances(GraphDev g, const u32 *pa
     float qn = g.norms ? g.norms[qa] : 0.f;
     if (ln == 0) ids[0] = pb[i];
     WSYNC();
-    dist_rows<LPR, NCH>(g, q, qn, ids, 1, d);
+    dist_rows<LPR, NCH>(g, q, qn, ids, 1, d, g.rows + (size_t)qa * g.row_stride);
     WSYNC();
     if (ln == 0) out[i] = d[0];
     WSYNC();

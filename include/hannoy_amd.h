@@ -66,6 +66,11 @@ typedef struct {
   double batch_frac;
   uint32_t batch_max;
   int32_t device;            /* HIP device ordinal; -1 = current */
+  /* 1 = strict mode: f32 distances in the reference's own x86 summation order (AVX2+FMA for
+   * dim >= 32, SSE for 16..31, scalar below; src/spaces/simple*.rs), bit for bit.  Slower; with
+   * batch_max = 1 the build then equals the reference run with one thread.  0 = wave order
+   * (within 1e-5 relative of it). */
+  int32_t x86_order;
 } hny_build_opts;
 
 /* replaces: what FrozenReader hands to the builder (src/parallel.rs:33-45) */

@@ -378,3 +378,38 @@ def test_gpu_ingest_matches_host_and_oracle(orc, hny, metric, kat):
         m = hny.HAMMING if k["codec"] == "binary" else hny.BQ_COSINE
         codes, _ = hny.encode_vectors(m, np.array([k["input"]], np.float32), gpu=True)
         assert [format(b, "08b") for b in codes[0]] == k["bytes_bin"]
+
+
+@pytest.mark.parametrize("metric,dim", [(0, 768), (1, 768), (0, 100), (1, 45), (0, 20), (1, 17), (0, 3),
+                                        (1, 7), (2, 33), (0, 1536)])
+def test_strict_mode_distances_equal_reference_x86_order(orc, hny, metric, dim):
+    """x86_order = 1: distances bit-identical to what the reference computes on an AVX2+FMA host
+    (AVX for dim >= 32, SSE for 16..31, scalar below; Manhattan scalar)."""
+    rng = np.random.default_rng(300 + metric * 11 + dim)
+    n = 200
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    lv = np.zeros(n, np.uint8)
+    lv[0] = 1
+    ds, items = _mk(orc, hny, metric, vecs, lv)
+    with hny.Builder(items, M=4, M0=8, x86_order=True) as b:
+        a = rng.integers(0, n, 1500).astype(np.uint32)
+        c = rng.integers(0, n, 1500).astype(np.uint32)
+        got = b.distances(a, c)
+    want = np.array([orc.distance(metric, orc.ORDER_X86, dim, ds.codes[i], ds.headers[i], ds.codes[j],
+                                  ds.headers[j]) for i, j in zip(a, c)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,frac,bmax", [(0, 1500, 768, 16, 32, 100, 0.0, 1),
+                                                             (1, 1200, 100, 8, 16, 40, 0.0, 1),
+                                                             (2, 800, 24, 6, 12, 24, 0.0, 1),
+                                                             (0, 3000, 96, 8, 16, 48, 0.1, 128)])
+def test_strict_mode_build_equals_reference_faithful_oracle(orc, hny, metric, n, dim, M, M0, ef, frac, bmax):
+    """x86_order = 1 and batch_max = 1: the GPU graph equals the oracle's restatement of the
+    reference run with one thread and its own x86 arithmetic (the mode KAT-1..5 pin)."""
+    rng = np.random.default_rng(n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=n))
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, batch_frac=frac, batch_max=0 if bmax == 1 else bmax)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax, x86_order=True)
+    _same_graph(g, o)
