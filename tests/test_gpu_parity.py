@@ -413,3 +413,36 @@ def test_strict_mode_build_equals_reference_faithful_oracle(orc, hny, metric, n,
     o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, batch_frac=frac, batch_max=0 if bmax == 1 else bmax)
     g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax, x86_order=True)
     _same_graph(g, o)
+
+
+def test_randomized_parameter_sweep(orc, hny):
+    """40 seeded random configurations (all metrics, odd dims, M == M0, ef below M0, ef = 1, many
+    entry points, duplicates, tiny inputs, sequential and batched schedules): GPU == oracle."""
+    import os
+    master = np.random.default_rng(2026)
+    for case in range(int(os.environ.get("HNY_SWEEP_CASES", "40"))):
+        metric = int(master.integers(0, 7))
+        dim = int(master.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 64, 100, 127, 200, 257, 520]))
+        M = int(master.choice([2, 3, 4, 6, 8, 12, 16, 24, 32]))
+        M0 = int(master.choice([M, min(64, 2 * M), min(64, 3 * M)]))
+        ef = int(master.choice([1, 2, 5, 16, 33, 64, 100, 130, 257]))
+        n = int(master.choice([1, 2, 5, 30, 200, 700, 1500]))
+        frac, bmax = [(0.0, 1), (0.25, 8), (0.5, 64), (1.0, 300), (0.05, 4096)][int(master.integers(0, 5))]
+        alpha = float(master.choice([1.0, 1.0, 1.2]))
+        rng = np.random.default_rng(1000 + case)
+        vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        if n > 10:  # exact duplicates and near-duplicates
+            vecs[rng.integers(0, n, n // 10)] = vecs[rng.integers(0, n, n // 10)]
+        levels = draw_levels(n, M, seed=case)
+        if case % 5 == 0:
+            levels[:] = min(int(levels.max()), 1)  # many entry points (all items on the top level)
+            if n > 60:
+                continue
+        ds = orc.Dataset.from_f32(metric, vecs, levels)
+        items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+        tag = f"case {case}: metric {metric} dim {dim} M {M} M0 {M0} ef {ef} n {n} frac {frac} bmax {bmax}"
+        o = orc.build(ds, M=M, M0=M0, ef=ef, alpha=alpha, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax)
+        g = hny.build(items, M=M, M0=M0, ef_construction=ef, alpha=alpha, batch_frac=frac, batch_max=bmax)
+        assert g.n_tie_pool_overflow == 0, tag
+        assert np.array_equal(g.offsets, o.offsets) and np.array_equal(g.nbrs, o.nbrs), tag
+        assert g.entry_points.tolist() == o.entry_points.tolist(), tag
