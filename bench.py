@@ -41,7 +41,9 @@ def parse():
     p.add_argument("--batch-max", type=int, default=0)
     p.add_argument("--queries", type=int, default=1000)
     p.add_argument("--ef-search", type=int, default=100)
-    p.add_argument("--cpu-sample", type=int, default=20000)
+    p.add_argument("--cpu-sample", type=int, default=0,
+                   help="items in the CPU baseline sample; 0 = calibrate for about --cpu-seconds of wall time")
+    p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-recall", action="store_true")
     p.add_argument("--seed", type=int, default=42)
@@ -231,11 +233,20 @@ def main():
                          "qps_incl_transfers": round(a.queries / ts, 1)}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle = port of the reference algorithm ----
-    if rank == 0 and world == 1 and not a.no_cpu and a.cpu_sample > 0:
+    if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import orc
         from tests.conftest import draw_levels
-        ns = min(a.cpu_sample, a.n)
         cores = os.cpu_count() or 1
+        ns = min(a.cpu_sample, a.n)
+        if ns <= 0:  # calibrate on 4000 items, then size the sample for ~cpu_seconds of wall time
+            nc = min(4000, a.n)
+            dsc = orc.Dataset(metric, a.dim, np.arange(nc, dtype=np.uint32), items.codes[:nc],
+                              items.headers[:nc], draw_levels(nc, a.M, a.seed))
+            t1 = time.perf_counter()
+            orc.build(dsc, M=a.M, M0=M0, ef=a.ef, order=orc.ORDER_X86, threads=cores)
+            rate = nc / max(time.perf_counter() - t1, 1e-3)
+            # the per-insert cost grows with the index: assume half the calibrated rate
+            ns = int(min(a.n, max(10000, min(200000, 0.5 * rate * a.cpu_seconds))))
         lv = draw_levels(ns, a.M, a.seed)
         ds = orc.Dataset(metric, a.dim, np.arange(ns, dtype=np.uint32), items.codes[:ns],
                          items.headers[:ns], lv)
@@ -248,6 +259,14 @@ def main():
                       f"{cores} threads (rayon-like), AVX2+FMA kernels; a smaller index is cheaper "
                       f"per insert than the 1M one, so this flatters the CPU",
             "seconds": round(tc, 2)}
+        full = os.path.join(ROOT, "profiles", "r01_c2_full_scale_recall_parity.json")
+        if default_c2 and os.path.exists(full):  # one-off measurement of the same baseline at full size
+            with open(full) as f:
+                fj = json.load(f)
+            out["cpu_baseline"]["full_size_run"] = {
+                "vectors_per_s": round(fj["cpu_vec_per_s"], 1), "seconds": round(fj["cpu_build_s"], 1),
+                "cores": fj["cores"], "recall_at_10": fj["recall_cpu_built_cpu_search"],
+                "source": "profiles/r01_c2_full_scale_recall_parity.json (scripts/recall_parity_full.py)"}
         # recall parity on the sample: CPU-built vs GPU-built graph, both searched by the oracle
         if not a.no_recall and a.queries:
             sub = H.ItemSet(metric, a.dim, ds.ids, ds.codes, ds.headers, lv)

@@ -984,13 +984,6 @@ __global__ __launch_bounds__(64) void k_prune(GraphDev g, PruneArgs a) {
 // every candidate row is read from HBM once (prefetched one candidate ahead) and compared against
 // the selected rows held in LDS; the 4 waves split the selected rows.  Same distances, same result.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int NCH>
-__device__ __forceinline__ float pair_distance(const GraphDev &g, const float4 (&a)[NCH], float an,
-                                               const float4 (&b)[NCH], float bn) {
-  if (g.mclass == MC_BIN) return finalize_bin(g, butterfly_u32<LPR>(partial_bin<NCH>(a, b)), an, bn);
-  return finalize_f32(g, butterfly_f32<LPR>(partial_f32<NCH>(g.mclass, a, b)), an, bn);
-}
-
 struct WgPruneLds {
   u64 *S;          // [HNY_MAX_CAP] selected keys
   u32 *s_ids;      // [HNY_MAX_CAP]
