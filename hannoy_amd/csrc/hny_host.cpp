@@ -248,7 +248,9 @@ struct hny_builder {
   DevBuf<u32> d_l0_ids, d_l0_cnt, d_up_ids, d_up_cnt, d_order, d_eps, d_bits, d_vlog, d_cand_n,
       d_seg_start, d_nseg, d_deferred, d_fin_cnt0, d_fin_cntu, d_d0_ids, d_du_ids;
   DevBuf<unsigned char> d_has_vec, d_deleted;
-  DevBuf<u64> d_old_recs;
+  DevBuf<u64> d_old_recs, d_lkey_a, d_lkey_b, d_perm_a, d_perm_b;
+  DevBuf<u32> d_eps0;
+  bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
   DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
@@ -808,6 +810,12 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_vals_b.alloc(b->max_ops));
   HIP_TRY(b->d_seg_start.alloc(b->max_ops));
   HIP_TRY(b->d_nseg.alloc(16));
+  b->locality = env_int("HNY_NO_LOCALITY", 0) == 0;
+  HIP_TRY(b->d_lkey_a.alloc(cand_rows));
+  HIP_TRY(b->d_lkey_b.alloc(cand_rows));
+  HIP_TRY(b->d_perm_a.alloc(cand_rows));
+  HIP_TRY(b->d_perm_b.alloc(cand_rows));
+  HIP_TRY(b->d_eps0.alloc(cand_rows));
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, (u32)b->max_ops, st));
@@ -1024,6 +1032,36 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     HIP_TRY(next_sync_event(b, &ev));
     HIP_TRY(hipEventRecord(ev, b->stream2));
     HIP_TRY(hipStreamWaitEvent(b->stream, ev, 0));
+    return HNY_OK;
+  }
+  if (L == 0 && b->locality && b->max_level >= 1 && cnt >= 2048) {
+    // level-0 batch in LOCALITY ORDER: (1) greedy descent for every member, recording the closest
+    // node of the last greedy layers as a coarse-to-fine key; (2) sort the members by that key;
+    // (3) layer-0 beam search and prune in that order, so that the waves running at the same time
+    // work in the same region of the graph and share candidate rows in L2 / Infinity Cache.  Results
+    // are stored per member: the build is unchanged, only its memory traffic.
+    const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
+    WalkArgs d = walk_args(0, lo, hi, queues + 0);
+    d.descend_only = 1;
+    d.eps_out = b->d_eps0.p;
+    d.key_out = b->d_lkey_a.p;
+    prof_begin(b, EV_WALK);
+    HIP_TRY(hnyk_walk(b->g, d, b->shape, grid, b->stream));
+    HIP_TRY(hnyk_iota_u64(b->d_perm_a.p, lo, cnt, b->stream));
+    size_t tmp = b->sort_tmp_bytes;
+    HIP_TRY(hnyk_sort_pairs48(b->d_sort_tmp.p, tmp, b->d_lkey_a.p, b->d_lkey_b.p, b->d_perm_a.p,
+                              b->d_perm_b.p, cnt, b->stream));
+    WalkArgs w = walk_args(0, lo, hi, queues + 1);
+    w.first = 0;
+    w.eps_in = b->d_eps0.p;
+    w.perm = b->d_perm_b.p;
+    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+    prof_end(b);
+    PruneArgs p = prune_args(0, lo, hi);
+    p.perm = b->d_perm_b.p;
+    prof_begin(b, EV_PRUNE);
+    HIP_TRY(launch_prune(p, b->stream));
+    prof_end(b);
     return HNY_OK;
   }
   const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);

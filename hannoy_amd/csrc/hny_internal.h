@@ -90,6 +90,16 @@ struct WalkArgs {
   u32 *vlog;        // [grid][log_cap]
   u32 log_cap;
   u32 *queue;       // work counter, zeroed before the launch
+  // locality-ordered processing (DESIGN.md "processing order"): results are stored per member, so
+  // the ORDER in which members are processed is free.  descend_only: run the greedy descent down to
+  // layer+1, write the closest node (eps_out) and a hierarchical locality key (key_out), no ef walk.
+  // eps_in: start the ef walk at `layer` from eps_in[m].  perm: processing order (queue index ->
+  // member).
+  int descend_only;
+  u32 *eps_out;
+  u64 *key_out;
+  const u32 *eps_in;
+  const u64 *perm;
   u32 knn_k;        // reader mode: wanted hits (exhaustive fallback below that, reader.rs:771-795)
   u32 knn_ef;       // reader mode: opt.ef of the query builder
 };
@@ -104,6 +114,7 @@ struct PruneArgs {
   u32 rcap;
   u64 *sel;
   u32 sel_stride, cap_sel, batch_level;
+  const u64 *perm;  // processing order (index -> member), or null
 };
 
 struct EmitArgs {
@@ -142,6 +153,9 @@ hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, i
                          hipStream_t st);
 hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
                            u64 *vals_out, u32 n, hipStream_t st);
+hipError_t hnyk_sort_pairs48(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
+                             u64 *vals_out, u32 n, hipStream_t st);
+hipError_t hnyk_iota_u64(u64 *p, u32 base, u32 n, hipStream_t st);
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st);
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);

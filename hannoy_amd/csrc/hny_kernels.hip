@@ -797,6 +797,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
     if (ln == 0) m = a.lo + atomicAdd(a.queue, 1u);
     m = uni(m);
     if (m >= a.hi) break;
+    if (a.perm) m = uni((u32)a.perm[m - a.lo]); // locality order; results stay indexed by member
     const unsigned char *qrow;
     float qn = 0.f;
     if (a.q_rows) {
@@ -816,6 +817,10 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
       n_eps = (int)a.n_entry_points;
       if (ln < n_eps) eps[ln] = a.entry_points[ln];
       start_layer = g.max_level;
+    } else if (a.eps_in) { // resume after a descend_only launch
+      n_eps = 1;
+      if (ln == 0) eps[0] = a.eps_in[m];
+      start_layer = a.layer;
     } else { // :316-321 eps = what was selected on the layer above
       const u64 *sl = a.sel + (size_t)m * a.sel_stride +
                       (size_t)(a.batch_level - (a.layer + 1)) * (a.cap_sel + 1);
@@ -824,14 +829,19 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
       start_layer = a.layer;
     }
     WSYNC();
+    u64 lkey = 0;
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
+      if (last && a.descend_only) break;
       walk_one_layer<LPR, NCH>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                nb_d, evals, err_iter, qrow);
       if (last) break;
       // :305-306 eps = [closest]
-      if (ln == 0) eps[0] = (u32)(s.res[0] >> 1) & 0x7FFFFFFFu;
+      const u32 closest = uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
+      if (ln == 0) eps[0] = closest;
       n_eps = 1;
+      // locality key: the closest node of the last three greedy layers, coarse to fine
+      lkey = (lkey << 16) | (u64)((u32)g.upper_idx[closest] & 0xFFFFu);
       // walk_layer owns a fresh visited set; Reader::hnsw_search shares `path` across the greedy
       // layers and clears it once before layer 0 (reader.rs:731-743)
       if (!a.reader_mode || layer == a.layer + 1) {
@@ -839,6 +849,14 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
         visited_clear(vis);
       }
       WSYNC();
+    }
+    if (a.descend_only) { // (a batch whose level equals max_level has no greedy layer: eps stay)
+      if (ln == 0) {
+        a.eps_out[m] = eps[0];
+        a.key_out[m - a.lo] = lkey & 0xFFFFFFFFFFFFull;
+      }
+      WSYNC();
+      continue;
     }
     // result, ascending (res.into_vec() is re-sorted by robust_prune anyway, :573)
     for (int e = ln; e < s.res_len; e += 64) {
@@ -1175,7 +1193,8 @@ __global__ __launch_bounds__(256) void k_prune_wg(GraphDev g, PruneArgs a, int S
   WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride);
   const int tid = threadIdx.x;
   u64 evals = 0;
-  for (u32 m = a.lo + blockIdx.x; m < a.hi; m += gridDim.x) {
+  for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
+    const u32 m = a.perm ? (u32)a.perm[mi - a.lo] : mi; // same locality order as the walk
     const int n = (int)a.cand_n[m];
     for (int e = tid; e < n; e += blockDim.x) list[e] = a.cand[(size_t)m * a.rcap + e];
     __syncthreads();
@@ -1823,4 +1842,18 @@ hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *ke
                            u64 *vals_out, u32 n, hipStream_t st) {
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
                                    0, 64, st);
+}
+hipError_t hnyk_sort_pairs48(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
+                             u64 *vals_out, u32 n, hipStream_t st) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
+                                   0, 48, st);
+}
+__global__ void k_iota_u64(u64 *p, u32 base, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (u64)(base + i);
+}
+hipError_t hnyk_iota_u64(u64 *p, u32 base, u32 n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_iota_u64, dim3((n + 255) / 256), dim3(256), 0, st, p, base, n);
+  return hipGetLastError();
 }
