@@ -446,3 +446,34 @@ def test_randomized_parameter_sweep(orc, hny):
         assert g.n_tie_pool_overflow == 0, tag
         assert np.array_equal(g.offsets, o.offsets) and np.array_equal(g.nbrs, o.nbrs), tag
         assert g.entry_points.tolist() == o.entry_points.tolist(), tag
+
+
+@pytest.mark.parametrize("metric,dim", [(0, 48), (3, 256)])
+def test_locality_ordered_batches_equal_oracle(orc, hny, metric, dim):
+    """Batches of >= 2048 members take the locality-ordered path (descent -> sort -> walk/prune in
+    that order).  Only the processing order changes: the graph must still equal the oracle's, also
+    when the batch is searched in two separate member ranges (the multi-GPU sharding)."""
+    rng = np.random.default_rng(77 + dim)
+    n = 14000
+    centres = rng.uniform(-1, 1, (20, dim))
+    vecs = (centres[rng.integers(0, 20, n)] + 0.2 * rng.normal(size=(n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, 16, seed=5))
+    o = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=4096, threads=8)
+    g = hny.build(items, M=16, M0=32, ef_construction=64, batch_frac=1.0, batch_max=4096)
+    _same_graph(g, o)
+    with hny.Builder(items, M=16, M0=32, ef_construction=64, batch_frac=1.0, batch_max=4096) as b:
+        big = 0
+        while True:
+            bt = b.next_batch()
+            if bt.count == 0:
+                break
+            if bt.count >= 4096:  # two "ranks" on one GPU
+                big += 1
+                b.search(0, bt.count // 2)
+                b.search(bt.count // 2, bt.count)
+            else:
+                b.search(0, bt.count)
+            b.apply()
+        g2 = b.finish()
+    assert big >= 1
+    _same_graph(g2, o)
