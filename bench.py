@@ -191,10 +191,14 @@ def main():
         with open(pmc_file) as f:
             pk = json.load(f).get("k_walk")
         if pk:
-            roof["traffic"] = int(pk["hbm_bytes_per_launch"])
+            total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
+            roof["traffic"] = int(total / max(1, graph.n_walk_launches))
             roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_tuned.json: rocprofv3 --pmc FETCH_SIZE / "
-                                      "WRITE_SIZE passes of this command, 2x FETCH + WRITE, "
-                                      f"{pk['launches']} k_walk launches")
+                                      "WRITE_SIZE passes of this command, 2x FETCH + WRITE summed over "
+                                      f"the {pk['launches']} k_walk dispatches of one build, divided by the "
+                                      "timed launches (a level-0 batch = descent + key sort + layer-0 "
+                                      "walk under one HIP-event pair); FETCH_SIZE counts Infinity-Cache "
+                                      "hits too, so this is L2-to-fabric traffic, an upper bound on HBM")
 
     out = {
         "metric": "vectors indexed/sec (build) + recall@10, 1M x 768 Cosine M=16 efC=100",
