@@ -235,6 +235,14 @@ def main():
         out["recall_at_10"] = round(recall_at_k(ids, counts, truth), 4)
         out["search"] = {"queries": a.queries, "ef_search": a.ef_search,
                          "qps_incl_transfers": round(a.queries / ts, 1)}
+        # throughput of the batched searcher on a large query set (same distribution, no ground truth)
+        nqs = 32768
+        qb = gen_data(torch, nqs, a.dim, a.data, a.seed + 2000, dev).cpu().numpy()
+        qbc, qbh = H.encode_vectors(metric, qb)
+        builder.search_knn(qbc[:4096], qbh[:4096], k=10, ef_search=a.ef_search)  # warm-up
+        t1 = time.perf_counter()
+        builder.search_knn(qbc, qbh, k=10, ef_search=a.ef_search)
+        out["search"]["qps_batch_32768_incl_transfers"] = round(nqs / (time.perf_counter() - t1), 1)
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle = port of the reference algorithm ----
     if rank == 0 and world == 1 and not a.no_cpu:

@@ -1417,8 +1417,11 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
   HIP_TRY(dcn.alloc(chunk));
   const bool has_norm = b->g.norms != nullptr;
   std::vector<float> qn(chunk);
-  std::vector<u64> hc((size_t)chunk * rcap);
+  DevBuf<u64> dtop;
+  HIP_TRY(dtop.alloc((size_t)chunk * k));
+  std::vector<u64> hc((size_t)chunk * k);
   std::vector<u32> hn(chunk);
+  u32 *queues = b->d_nseg.p + 4;
   for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
     uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
     int rc = upload_rows((const unsigned char *)qvectors + q0 * qstride, qstride, vb, cnt,
@@ -1449,16 +1452,34 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
-    w.queue = b->d_nseg.p + 4;
-    HIP_TRY(hipMemsetAsync(w.queue, 0, 4, b->stream));
-    HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(cnt, b->walk_slots), b->stream));
-    HIP_TRY(hipMemcpyAsync(hc.data(), dcand.p, (size_t)cnt * rcap * 8, hipMemcpyDeviceToHost, b->stream));
+    w.queue = queues;
+    HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
+    const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
+    if (b->locality && b->max_level >= 1 && cnt >= 2048) {
+      // same locality ordering as the build: descent -> sort the queries by their region -> layer 0
+      WalkArgs d = w;
+      d.descend_only = 1;
+      d.eps_out = b->d_eps0.p;
+      d.key_out = b->d_lkey_a.p;
+      HIP_TRY(hnyk_walk(b->g, d, b->shape, grid, b->stream));
+      HIP_TRY(hnyk_iota_u64(b->d_perm_a.p, 0, cnt, b->stream));
+      size_t tmp = b->sort_tmp_bytes;
+      HIP_TRY(hnyk_sort_pairs48(b->d_sort_tmp.p, tmp, b->d_lkey_a.p, b->d_lkey_b.p, b->d_perm_a.p,
+                                b->d_perm_b.p, cnt, b->stream));
+      w.first = 0;
+      w.eps_in = b->d_eps0.p;
+      w.perm = b->d_perm_b.p;
+      w.queue = queues + 1;
+    }
+    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+    HIP_TRY(hnyk_take_topk(dcand.p, dcn.p, rcap, k, cnt, dtop.p, b->stream));
+    HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (uint32_t i = 0; i < cnt; i++) { // drain_asc().take(k), reader.rs:797-798
       uint32_t c = std::min<uint32_t>(k, hn[i]);
       for (uint32_t j = 0; j < c; j++) {
-        u64 e = hc[(size_t)i * rcap + j];
+        u64 e = hc[(size_t)i * k + j];
         out_ids[(q0 + i) * k + j] = b->ids[(uint32_t)(e & 0xFFFFFFFFull)];
         uint32_t db = (uint32_t)(e >> 32);
         memcpy(&out_dists[(q0 + i) * k + j], &db, 4);

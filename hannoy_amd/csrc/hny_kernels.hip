@@ -1848,6 +1848,21 @@ hipError_t hnyk_sort_pairs48(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
                                    0, 48, st);
 }
+// drain_asc().take(k) (reader.rs:797-798): the k best of every query's sorted result row
+__global__ void k_take_topk(const u64 *cand, const u32 *cand_n, u32 rcap, u32 k, u32 n, u64 *out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (u64)n * k) return;
+  u32 q = (u32)(i / k), j = (u32)(i % k);
+  out[i] = j < cand_n[q] ? cand[(size_t)q * rcap + j] : HNY_OP_INVALID;
+}
+hipError_t hnyk_take_topk(const u64 *cand, const u32 *cand_n, u32 rcap, u32 k, u32 n, u64 *out,
+                          hipStream_t st) {
+  u64 total = (u64)n * k;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(k_take_topk, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cand, cand_n,
+                     rcap, k, n, out);
+  return hipGetLastError();
+}
 __global__ void k_iota_u64(u64 *p, u32 base, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (u64)(base + i);

@@ -109,7 +109,7 @@ def test_knn_search_equals_oracle_reader(orc, hny, metric, n, dim, M, M0, ef):
     distances (bit for bit in the wave order)."""
     rng = np.random.default_rng(n + dim)
     vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
-    qs = rng.uniform(-1, 1, (200, dim)).astype(np.float32)
+    qs = rng.uniform(-1, 1, (2500, dim)).astype(np.float32)  # >= 2048: locality-ordered search path
     ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=5))
     qc = orc.encode_vectors(metric, qs)
     qh = orc.make_headers(metric, dim, qc)
@@ -122,7 +122,7 @@ def test_knn_search_equals_oracle_reader(orc, hny, metric, n, dim, M, M0, ef):
         b.run()
         g2 = b.finish()
     _same_graph(g2, g)
-    oids, odists, ocounts = orc.search(ds, g, qc, qh, k=10, ef_search=50, order=orc.ORDER_WAVE)
+    oids, odists, ocounts = orc.search(ds, g, qc, qh, k=10, ef_search=50, order=orc.ORDER_WAVE, threads=8)
     assert np.array_equal(counts, ocounts)
     assert np.array_equal(ids, oids)
     assert np.array_equal(dists.view(np.uint32), odists.view(np.uint32))
