@@ -209,7 +209,7 @@ def main():
         "config": {"workload": f"C2: {a.n} x {a.dim} {a.metric}, M={a.M} M0={M0} efC={a.ef}, "
                                f"{a.data} synthetic vectors resident in HBM, 1 step = 1 full build",
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
-                   "batch_frac": builder.opts.batch_frac or 0.25,
+                   "batch_frac": builder.opts.batch_frac or 1.0,
                    "batch_max": builder.opts.batch_max or 32768,
                    "parallelism": f"item-sharded search x{world}, replicated graph",
                    "distance_order": "x86 (strict)" if a.x86_order else "wave"},

@@ -556,7 +556,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
 
   auto b = std::unique_ptr<hny_builder, void (*)(hny_builder *)>(new hny_builder(), hny_builder_destroy);
   b->o = o;
-  b->frac = o.batch_frac > 0.0 ? o.batch_frac : 0.25;
+  b->frac = o.batch_frac > 0.0 ? o.batch_frac : 1.0;
   b->bmax = o.batch_max ? o.batch_max : 32768u;
   b->incremental = inc != nullptr;
   uint32_t n16;
