@@ -26,7 +26,15 @@ EXPORTED = [
     "hny_builder_search_knn", "hny_vector_bytes", "hny_header_bytes", "hny_encode_vectors",
     "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels", "hny_build_incremental",
     "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
+    "hny_builder_nns", "hny_draw_levels_from_seed", "hny_builder_load",
 ]
+NNS_NONE = 0xFFFFFFFF  # by_item: the reference returns None
+
+
+class QueryOpts(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("ef_search", C.c_uint32), ("has_candidates", C.c_int32),
+                ("candidates", C.c_void_p), ("n_candidates", C.c_uint64), ("linear_below", C.c_uint32),
+                ("linear_below_ratio", C.c_float)]
 
 
 class HannoyError(RuntimeError):
@@ -119,6 +127,8 @@ def load_library():
     L.hny_builder_create_incremental.restype = C.c_int
     L.hny_builder_create_incremental.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), vp, C.c_uint64,
                                                  vp, C.c_uint64, C.POINTER(PrevGraph), C.POINTER(vp)]
+    L.hny_builder_load.restype = C.c_int
+    L.hny_builder_load.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(PrevGraph), C.POINTER(vp)]
     L.hny_builder_fill_gaps.restype = C.c_int
     L.hny_builder_fill_gaps.argtypes = [vp]
     L.hny_builder_create.restype = C.c_int
@@ -146,6 +156,10 @@ def load_library():
     L.hny_builder_search_knn.restype = C.c_int
     L.hny_builder_search_knn.argtypes = [vp, C.c_uint64, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32,
                                          vp, vp, vp]
+    L.hny_builder_nns.restype = C.c_int
+    L.hny_builder_nns.argtypes = [vp, C.POINTER(QueryOpts), C.c_uint64, vp, C.c_size_t, vp, vp, vp, vp, vp]
+    L.hny_draw_levels_from_seed.restype = C.c_int
+    L.hny_draw_levels_from_seed.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, vp]
     L.hny_vector_bytes.restype = C.c_size_t
     L.hny_vector_bytes.argtypes = [C.c_int32, C.c_uint32]
     L.hny_header_bytes.restype = C.c_size_t
@@ -177,6 +191,40 @@ def draw_levels(seed, M, n):
     out = np.zeros(n, np.uint8)
     _check(load_library().hny_draw_levels(seed, M, n, _p(out)))
     return out
+
+
+class StdRng:
+    """rand 0.8.5 `StdRng` as far as a build uses it: the 32-byte seed plus how many levels were
+    drawn so far (get_random_level costs one u32 each, hnsw.rs:113-119), so that one generator can
+    be carried across builds like `writer.builder(&mut rng)` does."""
+
+    def __init__(self, seed32, drawn=0):
+        self.seed = bytes(seed32)
+        assert len(self.seed) == 32
+        self.drawn = drawn
+
+    @classmethod
+    def from_seed(cls, seed32):
+        """SeedableRng::from_seed (the reference's test rng: [42; 32], src/tests/mod.rs:145-147)"""
+        return cls(seed32)
+
+    @classmethod
+    def seed_from_u64(cls, state):
+        """SeedableRng::seed_from_u64 (rand_core 0.6): PCG32 expansion (python.rs:261 uses 42)"""
+        out = b""
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & 0xFFFFFFFFFFFFFFFF
+            xs = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+            rot = state >> 59
+            out += (((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF).to_bytes(4, "little")
+        return cls(out)
+
+    def draw_levels(self, M, n):
+        out = np.zeros(n, np.uint8)
+        seed = (C.c_uint8 * 32).from_buffer_copy(self.seed)
+        _check(load_library().hny_draw_levels_from_seed(seed, self.drawn, M, n, _p(out)))
+        self.drawn += n
+        return out
 
 
 def vector_bytes(metric, dim):
@@ -337,8 +385,9 @@ def build_incremental(items, prev, to_insert, to_delete, **kw):
 class Builder:
     """Stepwise builder (hny_builder_*): vectors stay resident in HBM across reset()/rebuilds."""
 
-    def __init__(self, items, prev=None, to_insert=(), to_delete=(), **kw):
-        """prev given -> incremental builder on top of a stored graph (hny_builder_create_incremental)"""
+    def __init__(self, items, prev=None, to_insert=(), to_delete=(), load=False, **kw):
+        """prev given -> incremental builder on top of a stored graph (hny_builder_create_incremental);
+        with load=True the stored graph is only loaded for searching (hny_builder_load)"""
         self.items = items
         self.opts = make_opts(items.metric, items.dim, **kw)
         self._h = C.c_void_p()
@@ -346,6 +395,9 @@ class Builder:
         it = items.struct()
         if prev is None:
             _check(load_library().hny_builder_create(C.byref(self.opts), C.byref(it), C.byref(self._h)))
+        elif load:
+            pg, _keep = _prev_struct(prev)
+            _check(load_library().hny_builder_load(C.byref(self.opts), C.byref(it), C.byref(pg), C.byref(self._h)))
         else:
             ins = np.ascontiguousarray(to_insert, np.uint32)
             dl = np.ascontiguousarray(to_delete, np.uint32)
@@ -431,4 +483,29 @@ class Builder:
         _check(load_library().hny_builder_search_knn(self._h, nq, _p(qcodes), qcodes.shape[1],
                                                      _p(qheaders), k, ef_search, _p(ids),
                                                      _p(dists), _p(counts)))
+        return ids, dists, counts
+
+    def nns(self, qcodes=None, qheaders=None, k=10, ef_search=100, candidates=None, query_items=None,
+            linear_below=1000, linear_below_ratio=1.0):
+        """Reader::nns(k).ef_search(..).candidates(..).linear_below(..).by_vector / .by_item
+        (/root/reference/src/reader.rs:60-262).  counts == NNS_NONE where by_item returns None."""
+        qo = QueryOpts()
+        qo.k, qo.ef_search = k, ef_search
+        cand = None
+        if candidates is not None:
+            cand = np.ascontiguousarray(candidates, np.uint32)
+            qo.has_candidates, qo.candidates, qo.n_candidates = 1, cand.ctypes.data, len(cand)
+        qo.linear_below, qo.linear_below_ratio = linear_below, linear_below_ratio
+        if query_items is not None:
+            query_items = np.ascontiguousarray(query_items, np.uint32)
+            nq, qc, qs, qh, qi = len(query_items), None, 0, None, _p(query_items)
+        else:
+            qcodes = np.ascontiguousarray(qcodes, np.uint8)
+            qheaders = np.ascontiguousarray(qheaders, np.uint8)
+            nq, qc, qs, qh, qi = qcodes.shape[0], _p(qcodes), qcodes.shape[1], _p(qheaders), None
+        ids = np.zeros((nq, k), np.uint32)
+        dists = np.zeros((nq, k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        _check(load_library().hny_builder_nns(self._h, C.byref(qo), nq, qc, qs, qh, qi, _p(ids), _p(dists),
+                                              _p(counts)))
         return ids, dists, counts

@@ -74,6 +74,11 @@ class StdRngChaCha12 {
       key_[c] = (xs >> rot) | (xs << ((32 - rot) & 31));
     }
   }
+  explicit StdRngChaCha12(const uint8_t seed[32]) { // SeedableRng::from_seed: little-endian words
+    for (int c = 0; c < 8; c++)
+      key_[c] = (uint32_t)seed[4 * c] | ((uint32_t)seed[4 * c + 1] << 8) | ((uint32_t)seed[4 * c + 2] << 16) |
+                ((uint32_t)seed[4 * c + 3] << 24);
+  }
   uint32_t next_u32() {
     if (pos_ == 16) block();
     return out_[pos_++];
@@ -109,7 +114,7 @@ class StdRngChaCha12 {
 // get_random_level (hnsw.rs:113-119): WeightedIndex<f32>::new(probas).sample(rng), one draw per
 // item in ascending id order (hnsw.rs:142-149).  Reproduces what the reference draws from
 // StdRng::seed_from_u64(seed) (the Python binding's rng, python.rs:261).
-void draw_levels(uint64_t seed, uint32_t M, uint32_t n, uint8_t *out) {
+static void draw_levels_rng(StdRngChaCha12 &rng, uint64_t skip, uint32_t M, uint32_t n, uint8_t *out) {
   std::vector<float> p = level_probas(M);
   std::vector<float> cum; // running totals, last weight excluded
   float total = p[0];
@@ -129,7 +134,7 @@ void draw_levels(uint64_t seed, uint32_t M, uint32_t n, uint8_t *out) {
     sb -= 1;
     memcpy(&scale, &sb, 4);
   }
-  StdRngChaCha12 rng(seed);
+  for (uint64_t i = 0; i < skip; i++) (void)rng.next_u32(); // one u32 per earlier draw
   for (uint32_t s = 0; s < n; s++) {
     uint32_t u = (rng.next_u32() >> 9) | 0x3F800000u;
     float v;
@@ -139,6 +144,10 @@ void draw_levels(uint64_t seed, uint32_t M, uint32_t n, uint8_t *out) {
     while (l < cum.size() && cum[l] <= x) l++; // partition_point(|w| w <= x)
     out[s] = (uint8_t)l;
   }
+}
+void draw_levels(uint64_t seed, uint32_t M, uint32_t n, uint8_t *out) {
+  StdRngChaCha12 rng(seed);
+  draw_levels_rng(rng, 0, M, n, out);
 }
 
 // ---- f32 dot in the reference's x86 order, for Distance::new_header (cosine.rs:36-38,58-60):
@@ -399,6 +408,14 @@ const char *hny_version(void) { return "hannoy_amd 0.1.0 (gfx950)"; }
 size_t hny_vector_bytes(int32_t metric, uint32_t dim) { return vec_bytes(metric, dim); }
 size_t hny_header_bytes(int32_t metric) { return hdr_bytes(metric); }
 
+int hny_draw_levels_from_seed(const uint8_t seed[32], uint64_t skip, uint32_t M, uint64_t n, uint8_t *out) {
+  if (!seed || !out || M == 0 || n >= (1ull << 31))
+    return fail(HNY_ERR_INVALID_ARG, "hny_draw_levels_from_seed: bad argument");
+  StdRngChaCha12 rng(seed);
+  draw_levels_rng(rng, skip, M, (uint32_t)n, out);
+  return HNY_OK;
+}
+
 int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out) {
   if (!out || M == 0 || n >= (1ull << 31)) return fail(HNY_ERR_INVALID_ARG, "hny_draw_levels: bad argument");
   draw_levels(seed, M, (uint32_t)n, out);
@@ -528,6 +545,7 @@ struct IncrementalSpec {
   const uint32_t *to_delete;
   uint64_t n_delete;
   const hny_prev_graph *prev;
+  bool load_only = false; // Reader::open: the stored graph as it is, nothing gets (re)inserted
 };
 
 static int create_impl(const hny_build_opts *opts, const hny_items *items, const IncrementalSpec *inc,
@@ -673,7 +691,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     }
     if (!del_eps.empty() && n_new != n_old) max_level = 0; // :261-263
     for (uint32_t s = 0; s < n; s++)
-      if (in_new[s]) levels.push_back({s, (uint8_t)max_level}); // :267
+      if (in_new[s] && !inc->load_only) levels.push_back({s, (uint8_t)max_level}); // :267
     std::stable_sort(levels.begin(), levels.end(),
                      [](const std::pair<uint32_t, uint8_t> &x, const std::pair<uint32_t, uint8_t> &y) {
                        return x.second > y.second;
@@ -1322,6 +1340,14 @@ int hny_builder_create_incremental(const hny_build_opts *opts, const hny_items *
   return create_impl(opts, items, &inc, out);
 }
 
+int hny_builder_load(const hny_build_opts *opts, const hny_items *items, const hny_prev_graph *prev,
+                     hny_builder **out) {
+  if (!prev) return fail(HNY_ERR_INVALID_ARG, "null graph");
+  IncrementalSpec inc{nullptr, 0, nullptr, 0, prev};
+  inc.load_only = true;
+  return create_impl(opts, items, &inc, out);
+}
+
 int hny_builder_fill_gaps(hny_builder *b) {
   if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
   if (b->pos < b->order.size() || b->in_batch) return fail(HNY_ERR_INVALID_ARG, "build not finished");
@@ -1487,6 +1513,215 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
       out_counts[q0 + i] = c;
     }
   }
+  u64 stats[ST_COUNT] = {0};
+  HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
+    return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
+                stats[ST_ERR_ITER]);
+  return HNY_OK;
+}
+
+// QueryBuilder with .candidates() and/or by_item (reader.rs:60-262, 621-711, 809-896)
+int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const void *qvectors,
+                    size_t qstride, const void *qheaders, const uint32_t *query_items, uint32_t *out_ids,
+                    float *out_dists, uint32_t *out_counts) {
+  if (!b || !qo || !out_ids || !out_dists || !out_counts || qo->k == 0)
+    return fail(HNY_ERR_INVALID_ARG, "bad argument");
+  const bool by_item = query_items != nullptr;
+  if (!by_item && (!qvectors || !qheaders)) return fail(HNY_ERR_INVALID_ARG, "no queries");
+  if (qo->has_candidates && qo->n_candidates && !qo->candidates)
+    return fail(HNY_ERR_INVALID_ARG, "candidates missing");
+  if (!(qo->linear_below_ratio >= 0.f && qo->linear_below_ratio <= 1.f)) // reader.rs:253-256
+    return fail(HNY_ERR_INVALID_ARG, "linear scan threshold ratio must be between 0.0 and 1.0");
+  if (!qo->has_candidates && !by_item)
+    return hny_builder_search_knn(b, nq, qvectors, qstride, qheaders, qo->k, qo->ef_search, out_ids,
+                                  out_dists, out_counts);
+  if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
+  const uint32_t k = qo->k, ef = std::max(qo->ef_search, k); // reader.rs:746, 837
+  if (ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
+  HIP_TRY(hipSetDevice(b->device));
+  const uint32_t n = b->n;
+  auto exists = [&](uint32_t s) { return !b->incremental || !b->deleted[s]; };
+  auto slot_of = [&](uint32_t id) -> int64_t {
+    auto it = std::lower_bound(b->ids.begin(), b->ids.end(), id);
+    if (it == b->ids.end() || *it != id) return -1;
+    uint32_t s = (uint32_t)(it - b->ids.begin());
+    return exists(s) ? (int64_t)s : -1;
+  };
+  uint64_t n_items = 0;
+  for (uint32_t s = 0; s < n; s++) n_items += exists(s) ? 1 : 0;
+  // candidates ∩ item_ids as a mask over slots
+  std::vector<u32> mask;
+  std::vector<u32> cand_slots;
+  if (qo->has_candidates) {
+    mask.assign(((size_t)n + 31) / 32 + 1, 0u);
+    for (uint64_t i = 0; i < qo->n_candidates; i++) {
+      int64_t sl = slot_of(qo->candidates[i]);
+      if (sl >= 0) mask[(size_t)sl >> 5] |= 1u << (sl & 31);
+    }
+    for (uint32_t s = 0; s < n; s++)
+      if ((mask[s >> 5] >> (s & 31)) & 1u) cand_slots.push_back(s);
+  }
+  const uint32_t NONE = HNY_NNS_NONE;
+  // reader.rs:652-654 / 822-824
+  if (n_items == 0 || (qo->has_candidates && cand_slots.empty())) {
+    for (uint64_t i = 0; i < nq; i++) out_counts[i] = by_item ? NONE : 0u;
+    return HNY_OK;
+  }
+  // should_linear_scan, reader.rs:621-640
+  bool linear = false;
+  if (qo->has_candidates) {
+    const uint64_t cl = cand_slots.size();
+    linear = cl < (uint64_t)qo->linear_below && (float)cl / (float)n_items <= qo->linear_below_ratio;
+  }
+  if (!b->finalized) { // Reader::visit iterates Links bitmaps: ascending, deduplicated
+    HIP_TRY(hnyk_finalize_lists(b->d_l0_ids.p, b->d_fin_cnt0.p, b->n, b->o.M0, b->stream));
+    HIP_TRY(hnyk_finalize_lists(b->d_up_ids.p, b->d_fin_cntu.p, (u32)((size_t)b->n_upper * b->up_layers),
+                                b->o.M, b->stream));
+    b->finalized = true;
+  }
+  uint32_t rcap = 64;
+  while (rcap < std::max<uint32_t>(ef, (uint32_t)b->entry_points.size()) + 1) rcap *= 2;
+  const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
+  if (!by_item && qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
+  const uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
+  const bool has_norm = b->g.norms != nullptr;
+  DevBuf<unsigned char> dq;
+  DevBuf<float> dqn;
+  DevBuf<u64> dcand, dtop, dheap;
+  DevBuf<u32> dcn, dstatus, dqslots, dmembers, dfilter, dcslots;
+  if (!by_item) {
+    HIP_TRY(dq.alloc((size_t)chunk * b->g.row_stride));
+    HIP_TRY(dqn.alloc(chunk));
+  } else {
+    HIP_TRY(dqslots.alloc(chunk));
+  }
+  HIP_TRY(dcand.alloc((size_t)chunk * rcap));
+  HIP_TRY(dtop.alloc((size_t)chunk * k));
+  HIP_TRY(dcn.alloc(chunk));
+  HIP_TRY(dstatus.alloc(chunk));
+  HIP_TRY(dmembers.alloc(chunk));
+  if (qo->has_candidates) {
+    HIP_TRY(dfilter.alloc(mask.size()));
+    HIP_TRY(hipMemcpyAsync(dfilter.p, mask.data(), mask.size() * 4, hipMemcpyHostToDevice, b->stream));
+    if (linear) {
+      HIP_TRY(dcslots.alloc(cand_slots.size()));
+      HIP_TRY(hipMemcpyAsync(dcslots.p, cand_slots.data(), cand_slots.size() * 4, hipMemcpyHostToDevice,
+                             b->stream));
+    }
+  }
+  // search queue heaps: a modest one per resident wave first; queries that outgrow it run again
+  // with room for every item (the queue never holds more than the visited set)
+  const uint32_t heap_small = (uint32_t)std::min<uint64_t>((uint64_t)n + 1, 16384);
+  const uint32_t heap_full = n + 1;
+  uint32_t grid_small = std::min<uint32_t>(chunk, b->walk_slots);
+  if (!linear) HIP_TRY(dheap.alloc((size_t)grid_small * heap_small));
+  DevBuf<u64> dheap_full;
+  uint32_t grid_full = 0;
+  std::vector<float> qn(chunk);
+  std::vector<u32> qs(chunk), members(chunk), hn(chunk), hst(chunk);
+  std::vector<u64> hc((size_t)chunk * k);
+  u32 *queues = b->d_nseg.p + 4;
+  for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+    uint32_t n_mem = 0;
+    if (by_item) {
+      for (uint32_t i = 0; i < cnt; i++) {
+        int64_t sl = slot_of(query_items[q0 + i]); // item_vector(..)? else Ok(None), reader.rs:826
+        qs[i] = sl >= 0 ? (uint32_t)sl : 0u;
+        hn[i] = 0;
+        if (sl >= 0) members[n_mem++] = i;
+        else out_counts[q0 + i] = NONE;
+      }
+      HIP_TRY(hipMemcpyAsync(dqslots.p, qs.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, b->stream));
+    } else {
+      int rc = upload_rows((const unsigned char *)qvectors + q0 * qstride, qstride, vb, cnt, b->g.row_stride,
+                           dq.p, b->stream);
+      if (rc) return rc;
+      if (has_norm) {
+        for (uint32_t i = 0; i < cnt; i++)
+          memcpy(&qn[i], (const unsigned char *)qheaders + (q0 + i) * hb, 4);
+        HIP_TRY(hipMemcpyAsync(dqn.p, qn.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, b->stream));
+      }
+      for (uint32_t i = 0; i < cnt; i++) members[n_mem++] = i;
+    }
+    if (n_mem == 0) continue;
+    HIP_TRY(hipMemcpyAsync(dmembers.p, members.data(), (size_t)n_mem * 4, hipMemcpyHostToDevice, b->stream));
+    NnsArgs a{};
+    a.q_slots = dqslots.p;
+    a.q_rows = dq.p;
+    a.q_norms = has_norm && !by_item ? dqn.p : nullptr;
+    a.q_stride = b->g.row_stride;
+    a.members = dmembers.p;
+    a.n_members = n_mem;
+    a.filter = qo->has_candidates ? dfilter.p : nullptr;
+    a.by_item = by_item ? 1 : 0;
+    a.k = k;
+    a.ef_main = ef;
+    a.ef_opt = qo->ef_search;
+    a.entry_points = b->d_eps.p;
+    a.n_entry_points = (u32)b->entry_points.size();
+    a.cand = dcand.p;
+    a.cand_n = dcn.p;
+    a.rcap = rcap;
+    a.bits = b->d_bits.p;
+    a.bits_words = b->bits_words;
+    a.vlog = b->d_vlog.p;
+    a.log_cap = b->log_cap;
+    a.queue = queues;
+    a.status = dstatus.p;
+    a.cand_slots = dcslots.p;
+    a.n_cand_slots = (u32)cand_slots.size();
+    HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
+    if (linear) {
+      HIP_TRY(hnyk_nns_linear(b->g, a, b->shape, (int)std::min<uint32_t>(n_mem, b->walk_slots), b->stream));
+    } else {
+      a.heap = dheap.p;
+      a.heap_cap = heap_small;
+      HIP_TRY(hnyk_nns_filtered(b->g, a, b->shape, (int)std::min<uint32_t>(n_mem, grid_small), b->stream));
+      HIP_TRY(hipMemcpyAsync(hst.data(), dstatus.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
+      HIP_TRY(hipStreamSynchronize(b->stream));
+      uint32_t n_retry = 0;
+      for (uint32_t j = 0; j < n_mem; j++)
+        if (hst[members[j]]) members[n_retry++] = members[j];
+      if (n_retry && heap_small < heap_full) {
+        if (!grid_full) {
+          grid_full = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b->walk_slots, (2ull << 30) / ((uint64_t)heap_full * 8)));
+          HIP_TRY(dheap_full.alloc((size_t)grid_full * heap_full));
+        }
+        HIP_TRY(hipMemcpyAsync(dmembers.p, members.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, b->stream));
+        a.n_members = n_retry;
+        a.heap = dheap_full.p;
+        a.heap_cap = heap_full;
+        a.queue = queues + 1;
+        HIP_TRY(hnyk_nns_filtered(b->g, a, b->shape, (int)std::min<uint32_t>(n_retry, grid_full), b->stream));
+      } else if (n_retry) {
+        return fail(HNY_ERR_DEVICE, "search queue overflow");
+      }
+    }
+    HIP_TRY(hnyk_take_topk(dcand.p, dcn.p, rcap, k, cnt, dtop.p, b->stream));
+    HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(hst.data(), dstatus.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (uint32_t i = 0; i < cnt; i++) {
+      if (by_item && out_counts[q0 + i] == NONE && slot_of(query_items[q0 + i]) < 0) continue;
+      if (hst[i]) return fail(HNY_ERR_DEVICE, "search queue overflow");
+      uint32_t c = std::min<uint32_t>(k, hn[i]);
+      for (uint32_t j = 0; j < c; j++) {
+        u64 e = hc[(size_t)i * k + j];
+        out_ids[(q0 + i) * k + j] = b->ids[(uint32_t)(e & 0xFFFFFFFFull)];
+        uint32_t db = (uint32_t)(e >> 32);
+        memcpy(&out_dists[(q0 + i) * k + j], &db, 4);
+      }
+      out_counts[q0 + i] = c;
+    }
+  }
+  u64 stats[ST_COUNT] = {0};
+  HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
+    return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
+                stats[ST_ERR_ITER]);
   return HNY_OK;
 }
 

@@ -104,6 +104,37 @@ struct WalkArgs {
   u32 knn_ef;       // reader mode: opt.ef of the query builder
 };
 
+// Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
+// 809-896).  The search queue and `res` decouple here (the queue takes points the filter rejects), so
+// the queue is a real heap: 64-ary, in HBM, one per resident wave.
+struct NnsArgs {
+  const u32 *q_slots;          // by_item: slot of each query item
+  const unsigned char *q_rows; // by_vector: query rows / header norms
+  const float *q_norms;
+  u32 q_stride;
+  const u32 *members;          // queue index -> query index (retry pass), or null = identity
+  u32 n_members;
+  const u32 *filter;           // candidates as a bitset over slots, or null
+  int by_item;
+  u32 k, ef_main, ef_opt;      // count, max(ef, count), opt.ef
+  const u32 *entry_points;
+  u32 n_entry_points;
+  u64 *cand;                   // [n_queries][rcap] dist bits << 32 | slot, ascending
+  u32 *cand_n;
+  u32 rcap;
+  u32 *bits;
+  u32 bits_words;
+  u32 *vlog;
+  u32 log_cap;
+  u64 *heap;                   // [grid][heap_cap]
+  u32 heap_cap;
+  u32 *queue;
+  u32 *status;                 // [n_queries] 1 = the heap overflowed: run again with a larger one
+  // brute_force_search (reader.rs:667-711): the existing candidates, ascending
+  const u32 *cand_slots;
+  u32 n_cand_slots;
+};
+
 struct PruneArgs {
   const u32 *q_slots;
   u32 lo, hi;
@@ -144,6 +175,8 @@ struct LaunchShape {
 // kernels' host launchers (hny_kernels.hip)
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st);
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st);
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);

@@ -931,6 +931,400 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reader::nns with a candidates filter and/or by_item (reader.rs:301-369, 642-711, 809-896).
+// With a filter the `search_queue` takes every accepted point while `res` only takes the ones the
+// filter lets through (:356-360), so the two decouple: `res` stays the sorted LDS array (no
+// expanded bit, no tie pool), the queue becomes a real 64-ary min-heap in HBM (one coalesced
+// 512-B load per level on the way down), keyed dist bits << 32 | ~slot: smallest distance bits
+// first, larger id first among equals — BinaryHeap<(Reverse<OrderedFloat>, ItemId)> (:310).
+// ---------------------------------------------------------------------------------------------
+struct QHeap {
+  volatile u64 *h;
+  u32 size, cap;
+  u64 top;
+};
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    u64 o = (u64)__shfl_xor((long long)v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ bool qheap_push(QHeap &Q, u64 key) {
+  if (Q.size >= Q.cap) return false;
+  const int ln = threadIdx.x;
+  u32 j = Q.size++;
+  while (j > 0) {
+    const u32 p = (j - 1u) >> 6;
+    const u64 pk = uni(Q.h[p]);
+    if (pk <= key) break;
+    if (ln == 0) Q.h[j] = pk;
+    j = p;
+  }
+  if (ln == 0) Q.h[j] = key;
+  if (j == 0) Q.top = key;
+  __threadfence_block();
+  WSYNC();
+  return true;
+}
+
+__device__ __forceinline__ void qheap_pop(QHeap &Q) { // Q.size > 0
+  const int ln = threadIdx.x;
+  Q.size--;
+  if (Q.size == 0) return;
+  const u64 key = uni(Q.h[Q.size]);
+  u32 i = 0;
+  for (;;) {
+    const u32 base = (i << 6) + 1u;
+    if (base >= Q.size) break;
+    const u32 c = base + (u32)ln;
+    const u64 ck = c < Q.size ? Q.h[c] : ~0ull;
+    const u64 mn = wave_min_u64(ck);
+    if (mn >= key) break;
+    const int wl = __ffsll((long long)__ballot(ck == mn)) - 1; // keys are unique
+    if (ln == 0) Q.h[i] = mn;
+    if (i == 0) Q.top = mn;
+    i = base + (u32)wl;
+  }
+  if (ln == 0) Q.h[i] = key;
+  if (i == 0) Q.top = key;
+  __threadfence_block();
+  WSYNC();
+}
+
+// res.push (len != ef) / res.push_pop_max (len == ef) on the sorted array, reader.rs:361-365
+__device__ __forceinline__ void sorted_insert(u64 *res, int &len, u64 key, int ef, int rcap, u32 &err) {
+  const int ln = threadIdx.x;
+  int pos = 0;
+  for (int base = 0; base < len; base += 64) {
+    int e = base + ln;
+    bool lt = e < len && res[e] < key;
+    pos += __popcll(__ballot(lt));
+  }
+  const bool evict = (len == ef);
+  if (evict && pos == len) return; // the new entry is the max: pushed and popped at once
+  if (!evict && len >= rcap) {
+    err = 1;
+    return;
+  }
+  const int hi = evict ? len - 1 : len;
+  if (hi > pos) {
+    for (int base = (hi - 1) & ~63; base >= (pos & ~63); base -= 64) {
+      int e = base + ln;
+      bool mv = e >= pos && e < hi;
+      u64 v = mv ? res[e] : 0ull;
+      WSYNC();
+      if (mv) res[e + 1] = v;
+      WSYNC();
+    }
+  }
+  if (ln == 0) res[pos] = key;
+  WSYNC();
+  if (!evict) len++;
+}
+
+__device__ __forceinline__ bool in_filter(const u32 *filter, u32 excl, u32 id) {
+  if (id == excl) return false; // by_item: candidates.remove(item), reader.rs:840
+  return !filter || ((filter[id >> 5] >> (id & 31u)) & 1u);
+}
+
+// Visitor::visit at level 0 with `candidates` (reader.rs:301-369).  Returns 0, or 1 when the heap
+// is too small (the caller reports it and the host runs the query again with a larger one).
+template <int LPR, int NCH>
+__device__ int visit_filtered(const GraphDev &g, const float4 (&q)[NCH], float qn, int ef, const u32 *eps,
+                              int n_eps, u64 *res, int &res_len, int rcap, u32 &res_err, Visited &vis,
+                              u32 *nb_ids, float *nb_d, QHeap &Q, const u32 *filter, u32 excl,
+                              u64 &evals, u32 &err_iter, const unsigned char *qrow) {
+  const int ln = threadIdx.x;
+  res_len = 0;
+  Q.size = 0;
+  Q.top = ~0ull;
+  { // :316-325 every entry point is queued and visited; res takes it only if the filter does
+    u32 id = ln < n_eps ? eps[ln] : 0u;
+    bool isnew = visited_insert(vis, id, ln < n_eps);
+    u64 nmask = __ballot(isnew);
+    visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+    if (ln < n_eps) nb_ids[ln] = id;
+    WSYNC();
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_eps, nb_d, qrow);
+    evals += (u64)n_eps;
+    WSYNC();
+    for (int r = 0; r < n_eps; r++) {
+      const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
+      if (!qheap_push(Q, ((u64)db << 32) | (u64)(~idr))) return 1;
+      if (in_filter(filter, excl, idr)) sorted_insert(res, res_len, ((u64)db << 32) | idr, 0x7FFFFFFF, rcap, res_err);
+    }
+  }
+  for (u32 iter = 0;; iter++) {
+    if (iter > 4000000u || res_err) {
+      if (iter > 4000000u) err_iter = 1;
+      break;
+    }
+    if (Q.size == 0) break;
+    const u64 top = Q.top;
+    const float f = __uint_as_float((u32)(top >> 32));
+    const float fmax = res_len ? __uint_as_float(uni((u32)(res[res_len - 1] >> 32))) : 3.4028235e38f; // :337
+    if (f > fmax) break; // raw f32 compare, :338
+    qheap_pop(Q);
+    const u32 cslot = ~(u32)(top & 0xFFFFFFFFull);
+    for (int pass = g.incremental ? 0 : 1; pass < 2; pass++) {
+      u32 cap;
+      const u32 *nl = pass == 0 ? disk_ids(g, 0u, cslot, cap) : nbr_ids(g, 0u, cslot, cap);
+      if (!nl) continue;
+      u32 id = (u32)ln < cap ? nl[ln] : HNY_SENT;
+      bool valid = id != HNY_SENT;
+      bool isnew = visited_insert(vis, id, valid); // path.insert(point), :347
+      u64 nmask = __ballot(isnew);
+      if (!nmask) continue;
+      visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+      if (g.incremental) {
+        isnew = isnew && g.has_vec[id] != 0;
+        nmask = __ballot(isnew);
+        if (!nmask) continue;
+      }
+      const int n_new = __popcll(nmask);
+      const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
+      WSYNC();
+      if (isnew) nb_ids[rank] = id;
+      WSYNC();
+      dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow); // :350-353
+      evals += (u64)n_new;
+      WSYNC();
+      for (int r = 0; r < n_new; r++) { // ascending ids, like links.iter()
+        const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
+        if (res_len < ef || __uint_as_float(db) < fmax) { // :357
+          if (!qheap_push(Q, ((u64)db << 32) | (u64)(~idr))) return 1;
+          if (in_filter(filter, excl, idr)) sorted_insert(res, res_len, ((u64)db << 32) | idr, ef, rcap, res_err);
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *res = reinterpret_cast<u64 *>(smem);
+  u64 *pool = res + a.rcap;
+  u32 *nb_ids = reinterpret_cast<u32 *>(pool + HNY_POOL_CAP);
+  float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
+  u32 *eps = reinterpret_cast<u32 *>(nb_d + 64);
+  const int ln = threadIdx.x, t = ln % LPR;
+
+  Beam s; // greedy descent through the upper layers: the ordinary (unfiltered) walk
+  s.res = res;
+  s.pool = pool;
+  s.rcap = (int)a.rcap;
+  s.pool_over = 0;
+  s.err = 0;
+  s.res_len = 0;
+  s.pool_len = 0;
+  s.n_weird = 0;
+  s.tie_bits = 0;
+  s.dropped = false;
+  Visited vis;
+  vis.bits = a.bits + (size_t)blockIdx.x * a.bits_words;
+  vis.vlog = a.vlog + (size_t)blockIdx.x * a.log_cap;
+  vis.bits_words = a.bits_words;
+  vis.log_cap = a.log_cap;
+  vis.log_len = 0;
+  vis.log_over = false;
+  QHeap Q;
+  Q.h = a.heap + (size_t)blockIdx.x * a.heap_cap;
+  Q.cap = a.heap_cap;
+  Q.size = 0;
+  Q.top = ~0ull;
+  u64 evals = 0;
+  u32 err_iter = 0, log_over_cnt = 0, res_err = 0;
+
+  for (;;) {
+    u32 mi = 0;
+    if (ln == 0) mi = atomicAdd(a.queue, 1u);
+    mi = uni(mi);
+    if (mi >= a.n_members) break;
+    const u32 m = a.members ? uni(a.members[mi]) : mi;
+    const unsigned char *qrow;
+    float qn = 0.f;
+    u32 excl = HNY_SENT;
+    if (a.by_item) { // :826-828 the stored vector is the query
+      excl = uni(a.q_slots[m]);
+      qrow = g.rows + (size_t)excl * g.row_stride;
+      if (g.norms) qn = g.norms[excl];
+    } else {
+      qrow = a.q_rows + (size_t)m * a.q_stride;
+      if (a.q_norms) qn = a.q_norms[m];
+    }
+    float4 q[NCH];
+    load_row<LPR, NCH>(qrow, t, g.n16, q);
+    int n_eps;
+    if (a.by_item) { // Visitor::new(vec![item], 0, ef, Some(&candidates)), :842
+      n_eps = 1;
+      if (ln == 0) eps[0] = excl;
+      WSYNC();
+    } else { // :728-743 greedy descent, no filter, `path` shared and cleared before level 0
+      n_eps = (int)a.n_entry_points;
+      if (ln < n_eps) eps[ln] = a.entry_points[ln];
+      WSYNC();
+      for (u32 layer = g.max_level; layer >= 1u; layer--) {
+        walk_one_layer<LPR, NCH>(g, q, qn, layer, 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
+        const u32 closest = uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
+        WSYNC();
+        if (ln == 0) eps[0] = closest;
+        n_eps = 1;
+        if (layer == 1u) {
+          if (vis.log_over) log_over_cnt++;
+          visited_clear(vis);
+        }
+        WSYNC();
+      }
+    }
+    int res_len = 0;
+    int st = visit_filtered<LPR, NCH>(g, q, qn, (int)a.ef_main, eps, n_eps, res, res_len, (int)a.rcap, res_err,
+                                      vis, nb_ids, nb_d, Q, a.filter, excl, evals, err_iter, qrow);
+    int total = 0;
+    if (st == 0) {
+      for (int e = ln; e < res_len; e += 64) a.cand[(size_t)m * a.rcap + e] = res[e];
+      total = res_len;
+      if (total < (int)a.k) {
+        // exhaustive fallback (:771-795 / :864-890): restart from every item not on `path` yet
+        const u32 nwords = (g.n + 31) >> 5;
+        const int stop = a.by_item ? (int)a.k : (int)a.ef_opt;
+        u32 pos = 0;
+        while (pos < g.n) {
+          const u32 wbase = pos >> 5;
+          const u32 widx = wbase + (u32)ln;
+          u32 unv = 0u;
+          if (widx < nwords) {
+            unv = ~__hip_atomic_load(&vis.bits[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
+            if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
+          }
+          const u64 mk = __ballot(unv != 0u);
+          if (!mk) {
+            pos = (wbase + 64u) << 5;
+            continue;
+          }
+          const int l0 = __ffsll((long long)mk) - 1;
+          const u32 w0 = (u32)__builtin_amdgcn_readlane((int)unv, l0);
+          const u32 slot = ((wbase + (u32)l0) << 5) + (u32)__builtin_ctz(w0);
+          pos = slot + 1;
+          if (g.incremental && !g.has_vec[slot]) continue;
+          int ef2;
+          if (a.by_item) ef2 = (int)a.k - total;                                   // :878
+          else ef2 = (int)a.ef_opt > total ? (int)a.ef_opt - total : 0;           // :783
+          WSYNC();
+          if (ln == 0) eps[0] = slot;
+          WSYNC();
+          st = visit_filtered<LPR, NCH>(g, q, qn, ef2, eps, 1, res, res_len, (int)a.rcap, res_err, vis, nb_ids,
+                                        nb_d, Q, a.filter, excl, evals, err_iter, qrow);
+          if (st) break;
+          if (total + res_len > (int)a.rcap) {
+            res_err = 1;
+            break;
+          }
+          for (int e = ln; e < res_len; e += 64) a.cand[(size_t)m * a.rcap + total + e] = res[e];
+          total += res_len;
+          if (total >= stop) break;
+        }
+        if (st == 0 && !res_err) { // drain_asc()
+          __threadfence_block();
+          WSYNC();
+          for (int e = ln; e < total; e += 64) res[e] = a.cand[(size_t)m * a.rcap + e];
+          WSYNC();
+          for (int e = ln; e < total; e += 64) {
+            const u64 mine = res[e];
+            int rk = 0;
+            for (int k2 = 0; k2 < total; k2++) rk += res[k2] < mine ? 1 : 0;
+            a.cand[(size_t)m * a.rcap + rk] = mine;
+          }
+          WSYNC();
+        }
+      }
+    }
+    if (ln == 0) {
+      a.cand_n[m] = st ? 0u : (u32)total;
+      a.status[m] = st ? 1u : 0u;
+    }
+    if (vis.log_over) log_over_cnt++;
+    visited_clear(vis);
+  }
+  if (ln == 0) {
+    if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
+    if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
+    if (s.err || res_err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
+    if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
+  }
+}
+
+// brute_force_search (reader.rs:667-711): rank the existing candidates by distance.  The
+// BinaryHeap keeps `count` entries and replaces its top only by a strictly smaller distance while
+// walking the ids upwards — i.e. it keeps the `count` smallest (bits(d), id) pairs, which does not
+// depend on the evaluation order.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64, 4) void k_nns_linear(GraphDev g, NnsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *res = reinterpret_cast<u64 *>(smem);
+  u32 *nb_ids = reinterpret_cast<u32 *>(res + a.rcap);
+  float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
+  const int ln = threadIdx.x, t = ln % LPR;
+  u64 evals = 0;
+  u32 res_err = 0;
+  for (;;) {
+    u32 mi = 0;
+    if (ln == 0) mi = atomicAdd(a.queue, 1u);
+    mi = uni(mi);
+    if (mi >= a.n_members) break;
+    const u32 m = a.members ? uni(a.members[mi]) : mi;
+    const unsigned char *qrow;
+    float qn = 0.f;
+    if (a.by_item) {
+      const u32 qs = uni(a.q_slots[m]);
+      qrow = g.rows + (size_t)qs * g.row_stride;
+      if (g.norms) qn = g.norms[qs];
+    } else {
+      qrow = a.q_rows + (size_t)m * a.q_stride;
+      if (a.q_norms) qn = a.q_norms[m];
+    }
+    float4 q[NCH];
+    load_row<LPR, NCH>(qrow, t, g.n16, q);
+    int res_len = 0;
+    for (u32 base = 0; base < a.n_cand_slots; base += 64u) {
+      const int nc = (int)(a.n_cand_slots - base < 64u ? a.n_cand_slots - base : 64u);
+      WSYNC();
+      if (ln < nc) nb_ids[ln] = a.cand_slots[base + ln];
+      WSYNC();
+      dist_rows<LPR, NCH>(g, q, qn, nb_ids, nc, nb_d, qrow);
+      evals += (u64)nc;
+      WSYNC();
+      const u64 key = ln < nc ? (((u64)fbits(nb_d[ln]) << 32) | nb_ids[ln]) : ~0ull;
+      const u64 cur_max = (res_len == (int)a.k && res_len) ? uni(res[res_len - 1]) : ~0ull;
+      u64 want = __ballot(ln < nc && (res_len < (int)a.k || key < cur_max));
+      while (want) {
+        const int r = __ffsll((long long)want) - 1;
+        want &= want - 1ull;
+        const u64 kr = ((u64)(u32)__builtin_amdgcn_readlane((int)(key >> 32), r) << 32) |
+                       (u64)(u32)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), r);
+        sorted_insert(res, res_len, kr, (int)a.k, (int)a.rcap, res_err);
+      }
+    }
+    WSYNC();
+    for (int e = ln; e < res_len; e += 64) a.cand[(size_t)m * a.rcap + e] = res[e];
+    if (ln == 0) {
+      a.cand_n[m] = (u32)res_len;
+      a.status[m] = 0u;
+    }
+  }
+  if (ln == 0) {
+    if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
+    if (res_err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // robust_prune (hnsw.rs:565-597) on a list that is already sorted ascending by (bits(d), id).
 // list/sel keys: dist bits << 32 | slot.  `exists i in S: bits(d(c,i)*alpha) < bits(dq)` does not
 // depend on evaluation order, so S is tested RPI rows at a time with an early exit per chunk.
@@ -1709,6 +2103,22 @@ struct WalkLauncher {
   }
 };
 template <int L, int C>
+struct NnsFilteredLauncher {
+  static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
+    size_t lds = hnyk_walk_lds_bytes(a.rcap);
+    hipLaunchKernelGGL((k_nns_filtered<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
+struct NnsLinearLauncher {
+  static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
+    size_t lds = (size_t)a.rcap * 8 + 64 * 4 * 2;
+    hipLaunchKernelGGL((k_nns_linear<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
 struct PruneLauncher {
   static hipError_t run(const GraphDev &g, const PruneArgs &a, int grid, hipStream_t st) {
     size_t lds = (size_t)a.rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4);
@@ -1775,6 +2185,12 @@ size_t hnyk_walk_lds_bytes(u32 rcap) {
 
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<WalkLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<NnsFilteredLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<NnsLinearLauncher>(s, g, a, grid, st);
 }
 hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<PruneLauncher>(s, g, a, grid, st);

@@ -145,12 +145,17 @@ int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, co
 /* ---- stepwise build (what hny_build loops over; used by the multi-GPU driver) ---- */
 int hny_builder_create(const hny_build_opts *opts, const hny_items *items, hny_builder **out);
 /* stepwise form of hny_build_incremental: after the batches call hny_builder_fill_gaps once, then
- * hny_builder_finish.  With nothing to insert or delete this simply loads a stored graph into HBM
- * (e.g. for hny_builder_search_knn). */
+ * hny_builder_finish. */
 int hny_builder_create_incremental(const hny_build_opts *opts, const hny_items *items,
                                    const uint32_t *to_insert, uint64_t n_insert,
                                    const uint32_t *to_delete, uint64_t n_delete,
                                    const hny_prev_graph *prev, hny_builder **out);
+/* Reader::open (src/reader.rs:387-431): a stored graph (every Links record + Metadata.entry_points,
+ * max_level) and its items loaded into HBM as they are, for hny_builder_search_knn / hny_builder_nns.
+ * Nothing is inserted (an empty hny_builder_create_incremental would re-link the old entry points,
+ * like an empty Writer::build does, hnsw.rs:267). */
+int hny_builder_load(const hny_build_opts *opts, const hny_items *items, const hny_prev_graph *prev,
+                     hny_builder **out);
 int hny_builder_fill_gaps(hny_builder *b); /* fill_gaps_from_deleted, hnsw.rs:187, 334-415 */
 int hny_builder_reset(hny_builder *b); /* empty graph again, vectors stay resident in HBM */
 int hny_builder_next_batch(hny_builder *b, hny_batch *out);
@@ -168,6 +173,10 @@ void hny_builder_destroy(hny_builder *b);
 /* get_random_level (hnsw.rs:113-119) for n items in ascending id order, as the reference draws
  * them from StdRng::seed_from_u64(seed); what hny_build uses when items.levels == NULL */
 int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out);
+/* the same from StdRng::from_seed(seed) (the reference's test rng, src/tests/mod.rs:145-147) after
+ * `skip` earlier draws of the same generator (each level costs one u32), for a caller that keeps
+ * one rng across several builds like `writer.builder(&mut rng)` does */
+int hny_draw_levels_from_seed(const uint8_t seed[32], uint64_t skip, uint32_t M, uint64_t n, uint8_t *out);
 /* the schedule: batch size when n_done items are already inserted */
 uint32_t hny_batch_size(double batch_frac, uint32_t batch_max, uint64_t n_done);
 
@@ -180,6 +189,29 @@ int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot
 int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvectors, size_t qstride,
                            const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
                            float *out_dists, uint32_t *out_counts);
+
+/* ---- search with the rest of QueryBuilder (src/reader.rs:60-262): `.candidates(&bitmap)`
+ * (:200-203), `.linear_below()` / `.linear_below_ratio()` (:234-262) and `by_item` (:81-90).
+ * With candidates fewer than linear_below (and within the ratio) the candidates are ranked by
+ * brute force (should_linear_scan :621-640, brute_force_search :667-711); otherwise the HNSW walk
+ * runs with the filter applied to the result heap only (Visitor::visit :301-369), then the
+ * exhaustive fallback (:771-795 / :864-890).  query_items != NULL = by_item: one item id per query
+ * instead of qvectors/qheaders (which may then be NULL); out_counts[i] = HNY_NNS_NONE where the
+ * reference returns None (unknown item, or nothing can ever match, :822-826).  The cancel closure of
+ * the *_with_cancellation variants has no counterpart: a batch runs to completion. */
+#define HNY_NNS_NONE 0xFFFFFFFFu
+typedef struct {
+  uint32_t k;                 /* Reader::nns(count) */
+  uint32_t ef_search;         /* default 100 (reader.rs:23) */
+  int32_t has_candidates;     /* .candidates() given (it may be empty) */
+  const uint32_t *candidates; /* item ids, any order, duplicates and unknown ids allowed */
+  uint64_t n_candidates;
+  uint32_t linear_below;      /* default 1000 (reader.rs:28) */
+  float linear_below_ratio;   /* default 1.0 (reader.rs:31); must be in [0, 1] (:253-256) */
+} hny_query_opts;
+int hny_builder_nns(hny_builder *b, const hny_query_opts *opts, uint64_t n_queries, const void *qvectors,
+                    size_t qstride, const void *qheaders, const uint32_t *query_items, uint32_t *out_ids,
+                    float *out_dists, uint32_t *out_counts);
 
 /* ---- codecs: UnalignedVectorCodec::from_slice (src/unaligned_vector/{f32,binary,
  * binary_quantized}.rs) + Distance::new_header (cosine.rs:36-38 ...) ---- */

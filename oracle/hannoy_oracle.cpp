@@ -1221,14 +1221,16 @@ uint64_t orc_graph_distance_evals(const orc_graph *g) { return g->n_evals; }
 uint64_t orc_graph_links_added(const orc_graph *g) { return g->n_links; }
 
 /* ------------------------------------------------------------------ */
-/* Reader::nns().by_vector — reader.rs:301-369 (visit), 722-800 (hnsw_search) */
+/* Reader::nns() — reader.rs:301-369 (Visitor::visit), 621-640 (should_linear_scan), 642-665    */
+/* (nns_by_vec), 667-711 (brute_force_search), 722-800 (hnsw_search), 809-896 (nns_by_item)     */
 /* ------------------------------------------------------------------ */
-int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *items,
-               uint64_t n_records, const uint32_t *rec_item, const uint8_t *rec_layer,
-               const uint64_t *offsets, const uint32_t *nbrs, const uint32_t *entry_points,
-               uint32_t n_entry_points, uint32_t max_level, uint64_t n_queries, const void *qvecs,
-               size_t qstride, const void *qhdrs, uint32_t k, uint32_t ef_search, int32_t threads,
-               uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+int orc_search_ex(int32_t metric, int32_t order, uint32_t dim, const orc_items *items,
+                  uint64_t n_records, const uint32_t *rec_item, const uint8_t *rec_layer,
+                  const uint64_t *offsets, const uint32_t *nbrs, const uint32_t *entry_points,
+                  uint32_t n_entry_points, uint32_t max_level, uint64_t n_queries, const void *qvecs,
+                  size_t qstride, const void *qhdrs, uint32_t k, uint32_t ef_search, int32_t threads,
+                  const orc_query_opts *qo, uint32_t *out_ids, float *out_dists,
+                  uint32_t *out_counts) {
   uint32_t n = (uint32_t)items->n;
   Dist dist{metric, order, dim, vec_bytes(metric, dim)};
   size_t hsz = items->header_size;
@@ -1251,21 +1253,97 @@ int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *ite
     if (s < 0) return -3;
     ep_slots.push_back((uint32_t)s);
   }
+  /* QueryBuilder::candidates (reader.rs:200-203) as a mask over the stored items; ids that are not
+   * in the database never matter (brute_force_search skips them :686, the graph never reaches them) */
+  const bool has_cand = qo && qo->has_candidates;
+  const bool by_item = qo && qo->query_items;
+  std::vector<uint8_t> cand_mask;
+  std::vector<uint32_t> cand_slots; /* ascending */
+  if (has_cand) {
+    cand_mask.assign(n, 0);
+    for (uint64_t i = 0; i < qo->n_candidates; i++) {
+      int64_t s = slot_of(qo->candidates[i]);
+      if (s >= 0 && !cand_mask[s]) cand_mask[s] = 1;
+    }
+    for (uint32_t s = 0; s < n; s++)
+      if (cand_mask[s]) cand_slots.push_back(s);
+  }
+  /* should_linear_scan, reader.rs:621-640 */
+  bool linear = false;
+  if (has_cand && n > 0) {
+    uint64_t cl = cand_slots.size();
+    bool below_threshold = cl < (uint64_t)qo->linear_below;
+    bool below_ratio = (float)cl / (float)n <= qo->linear_below_ratio;
+    linear = below_threshold && below_ratio;
+  }
   std::atomic<int> err{0};
   auto run_query = [&](uint64_t qi, Scratch &path) {
-    const uint8_t *qv = (const uint8_t *)qvecs + qi * qstride;
-    const uint8_t *qh = (const uint8_t *)qhdrs + qi * hsz;
     out_counts[qi] = 0;
-    if (n == 0) return; /* reader.rs:652-654 */
+    const uint8_t *qv, *qh;
+    uint32_t excl = 0xFFFFFFFFu; /* by_item: candidates.remove(item) :840 */
+    /* :652-654 / :822-824 */
+    bool never = n == 0 || (has_cand && cand_slots.empty());
+    if (by_item) {
+      if (never) {
+        out_counts[qi] = 0xFFFFFFFFu; /* Ok(None) */
+        return;
+      }
+      int64_t s = slot_of(qo->query_items[qi]);
+      if (s < 0) { /* item_vector(..)? else return Ok(None) :826 */
+        out_counts[qi] = 0xFFFFFFFFu;
+        return;
+      }
+      /* :826-828 the stored vector re-encoded: same codec bytes, same header */
+      qv = (const uint8_t *)items->vectors + (size_t)s * items->stride;
+      qh = (const uint8_t *)items->headers + (size_t)s * hsz;
+      excl = (uint32_t)s;
+    } else {
+      if (never) return; /* Done(Vec::new()) */
+      qv = (const uint8_t *)qvecs + qi * qstride;
+      qh = (const uint8_t *)qhdrs + qi * hsz;
+    }
     uint64_t dummy = 0;
     auto qd = [&](uint32_t s) {
       dummy++;
       return dist(qv, qh, (const uint8_t *)items->vectors + (size_t)s * items->stride,
                   (const uint8_t *)items->headers + (size_t)s * hsz);
     };
+    auto emit = [&](const std::vector<Link> &sorted) { /* drain_asc().take(count) */
+      uint32_t cnt = (uint32_t)std::min<size_t>(k, sorted.size());
+      for (uint32_t i = 0; i < cnt; i++) {
+        out_ids[qi * k + i] = items->ids[sorted[i].id];
+        out_dists[qi * k + i] = sorted[i].d;
+      }
+      out_counts[qi] = cnt;
+    };
+    if (linear) { /* brute_force_search, reader.rs:667-711 (by_item: the item itself stays in) */
+      /* BinaryHeap<(OrderedFloat, id)> kept at <= count entries: the top (max by bits, then id) is
+       * replaced only by a strictly smaller distance (:695), compared by bit pattern */
+      std::vector<Link> heap; /* kept sorted ascending by link_key: back() is the top */
+      for (uint32_t s : cand_slots) {
+        float d = qd(s);
+        if (heap.size() >= k) {
+          if (!heap.empty() && f32_bits(heap.back().d) > f32_bits(d)) {
+            heap.pop_back();
+            Link l{d, s};
+            heap.insert(std::lower_bound(heap.begin(), heap.end(), link_key(l),
+                                         [](const Link &a, uint64_t kk) { return link_key(a) < kk; }),
+                        l);
+          }
+        } else {
+          Link l{d, s};
+          heap.insert(std::lower_bound(heap.begin(), heap.end(), link_key(l),
+                                       [](const Link &a, uint64_t kk) { return link_key(a) < kk; }),
+                      l);
+        }
+      }
+      emit(heap); /* into_sorted_vec :706 */
+      return;
+    }
     std::vector<Link> res;
-    /* Visitor::visit, reader.rs:301-369 (no candidate filter, no cancel) */
-    auto visit = [&](const std::vector<uint32_t> &eps, uint32_t level, size_t ef) {
+    auto in_filter = [&](uint32_t s) { return (!has_cand || cand_mask[s]) && s != excl; };
+    /* Visitor::visit, reader.rs:301-369 (no cancel) */
+    auto visit = [&](const std::vector<uint32_t> &eps, uint32_t level, size_t ef, bool filtered) {
       std::priority_queue<Link, std::vector<Link>, CandLess> sq;
       res.clear();
       auto res_insert = [&](const Link &l) {
@@ -1278,7 +1356,7 @@ int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *ite
         Link l{qd(ep), ep};
         sq.push(l);
         path.visit(ep);
-        res_insert(l);
+        if (!filtered || in_filter(ep)) res_insert(l); /* :322-324 */
       }
       while (!sq.empty()) {
         float f = sq.top().d;
@@ -1303,6 +1381,7 @@ int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *ite
           if (res.size() < ef || d < f_max) {
             Link l{d, p};
             sq.push(l);
+            if (filtered && !in_filter(p)) continue; /* :356-360 */
             if (res.size() == ef) {
               res_insert(l);
               res.pop_back();
@@ -1314,36 +1393,39 @@ int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *ite
       }
     };
     path.begin(n);
-    std::vector<uint32_t> eps = ep_slots;
-    /* reader.rs:732-741: the path bitmap is shared across the greedy layers */
-    for (uint32_t l = max_level; l >= 1; l--) {
-      visit(eps, l, 1);
-      if (err.load()) return;
-      eps.assign(1, res.front().id);
+    std::vector<uint32_t> eps;
+    size_t ef = std::max<size_t>(ef_search, k); /* :746 / :837 */
+    const bool filtered = has_cand || by_item;
+    if (by_item) {
+      eps.assign(1, excl); /* Visitor::new(vec![item], 0, ef, Some(&candidates)) :842 */
+    } else {
+      eps = ep_slots;
+      /* reader.rs:732-741: the path bitmap is shared across the greedy layers */
+      for (uint32_t l = max_level; l >= 1; l--) {
+        visit(eps, l, 1, false);
+        if (err.load()) return;
+        eps.assign(1, res.front().id);
+      }
+      path.begin(n); /* path.clear() :743 */
     }
-    path.begin(n); /* path.clear() :743 */
-    size_t ef = std::max<size_t>(ef_search, k); /* :746 */
-    visit(eps, 0, ef);
+    visit(eps, 0, ef, filtered);
     if (err.load()) return;
     std::vector<Link> neighbours = res;
-    if (neighbours.size() < k) { /* exhaustive fallback :771-795 */
+    if (neighbours.size() < k) { /* exhaustive fallback :771-795 / :864-890 */
       for (uint32_t s = 0; s < n; s++) {
         if (path.stamp[s] == path.epoch) continue;
-        size_t ef2 = ef_search > neighbours.size() ? ef_search - neighbours.size() : 0;
-        visit(std::vector<uint32_t>{s}, 0, ef2);
+        size_t ef2;
+        if (by_item) ef2 = k - neighbours.size(); /* :878 */
+        else ef2 = ef_search > neighbours.size() ? ef_search - neighbours.size() : 0; /* :783 */
+        visit(std::vector<uint32_t>{s}, 0, ef2, filtered);
         if (err.load()) return;
         for (const Link &l : res) neighbours.push_back(l);
-        if (neighbours.size() >= ef_search) break;
+        if (neighbours.size() >= (by_item ? (size_t)k : (size_t)ef_search)) break;
       }
       std::sort(neighbours.begin(), neighbours.end(),
                 [](const Link &a, const Link &b) { return link_key(a) < link_key(b); });
     }
-    uint32_t cnt = (uint32_t)std::min<size_t>(k, neighbours.size()); /* drain_asc().take(k) :797 */
-    for (uint32_t i = 0; i < cnt; i++) {
-      out_ids[qi * k + i] = items->ids[neighbours[i].id];
-      out_dists[qi * k + i] = neighbours[i].d;
-    }
-    out_counts[qi] = cnt;
+    emit(neighbours); /* drain_asc().take(k) :797 */
   };
   int nt = std::max(1, threads);
   std::atomic<uint64_t> next{0};
@@ -1359,6 +1441,17 @@ int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *ite
     });
   for (auto &t : th) t.join();
   return err.load();
+}
+
+int orc_search(int32_t metric, int32_t order, uint32_t dim, const orc_items *items,
+               uint64_t n_records, const uint32_t *rec_item, const uint8_t *rec_layer,
+               const uint64_t *offsets, const uint32_t *nbrs, const uint32_t *entry_points,
+               uint32_t n_entry_points, uint32_t max_level, uint64_t n_queries, const void *qvecs,
+               size_t qstride, const void *qhdrs, uint32_t k, uint32_t ef_search, int32_t threads,
+               uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+  return orc_search_ex(metric, order, dim, items, n_records, rec_item, rec_layer, offsets, nbrs,
+                       entry_points, n_entry_points, max_level, n_queries, qvecs, qstride, qhdrs, k,
+                       ef_search, threads, nullptr, out_ids, out_dists, out_counts);
 }
 
 /* ------------------------------------------------------------------ */

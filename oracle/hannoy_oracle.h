@@ -140,6 +140,26 @@ uint32_t orc_graph_max_level(const orc_graph *g);
 uint64_t orc_graph_distance_evals(const orc_graph *g);
 uint64_t orc_graph_links_added(const orc_graph *g);
 
+/* QueryBuilder options beyond count / ef_search (reader.rs:60-67, 200-262) */
+typedef struct {
+  int32_t has_candidates;      /* .candidates(&bitmap) given (may be empty) */
+  const uint32_t *candidates;  /* item ids, any order, may name items that do not exist */
+  uint64_t n_candidates;
+  const uint32_t *query_items; /* by_item (reader.rs:81-90): one item id per query instead of a
+                                * vector, or NULL; out_counts = 0xFFFFFFFF where the reference
+                                * returns None */
+  uint32_t linear_below;       /* default 1000 (reader.rs:28) */
+  float linear_below_ratio;    /* default 1.0 (reader.rs:31) */
+} orc_query_opts;
+
+int orc_search_ex(int32_t metric, int32_t order, uint32_t dim, const orc_items *items,
+                  uint64_t n_records, const uint32_t *rec_item, const uint8_t *rec_layer,
+                  const uint64_t *offsets, const uint32_t *nbrs, const uint32_t *entry_points,
+                  uint32_t n_entry_points, uint32_t max_level, uint64_t n_queries, const void *qvecs,
+                  size_t qstride, const void *qhdrs, uint32_t k, uint32_t ef_search, int32_t threads,
+                  const orc_query_opts *qo, uint32_t *out_ids, float *out_dists,
+                  uint32_t *out_counts);
+
 /* ---- search: Reader::nns().by_vector (reader.rs:301-369, 642-665, 722-800) ---- */
 /* graph given as exported records; queries are codec bytes + header. Returns
  * number of hits written per query in out_counts (<= k). */

@@ -25,6 +25,15 @@ def build_lib(force=False):
     return LIB
 
 
+NONE = 0xFFFFFFFF  # by_item: Ok(None)
+
+
+class QueryOpts(C.Structure):
+    _fields_ = [("has_candidates", C.c_int32), ("candidates", C.c_void_p), ("n_candidates", C.c_uint64),
+                ("query_items", C.c_void_p), ("linear_below", C.c_uint32),
+                ("linear_below_ratio", C.c_float)]
+
+
 class Opts(C.Structure):
     _fields_ = [("metric", C.c_int32), ("dim", C.c_uint32), ("M", C.c_uint32), ("M0", C.c_uint32),
                 ("ef_construction", C.c_uint32), ("alpha", C.c_float), ("order", C.c_int32),
@@ -91,6 +100,12 @@ def lib():
                                  C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
                                  C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
+        L.orc_search_ex.restype = C.c_int
+        L.orc_search_ex.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.POINTER(Items), C.c_uint64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,
+                                    C.POINTER(QueryOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_encode_key.argtypes = [C.c_uint16, C.c_uint8, C.c_uint32, C.c_uint8, C.c_void_p]
         L.orc_roaring_serialize.restype = C.c_size_t
         L.orc_roaring_serialize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -299,24 +314,41 @@ def build_incremental(ds, prev, to_insert, insert_levels, to_delete, **kw):
     return g
 
 
-def search(ds, graph, qcodes, qheaders, k=10, ef_search=100, order=ORDER_X86, threads=1):
-    """graph: anything with rec_item/rec_layer/offsets/nbrs/entry_points/max_level arrays."""
-    qcodes = np.ascontiguousarray(qcodes, np.uint8)
-    qheaders = np.ascontiguousarray(qheaders, np.uint8)
-    nq = qcodes.shape[0]
+def search(ds, graph, qcodes, qheaders, k=10, ef_search=100, order=ORDER_X86, threads=1,
+           candidates=None, query_items=None, linear_below=1000, linear_below_ratio=1.0):
+    """Reader::nns(k).ef_search(..).candidates(..).by_vector / by_item.
+    graph: anything with rec_item/rec_layer/offsets/nbrs/entry_points/max_level arrays.
+    query_items: item ids (by_item) instead of qcodes/qheaders; counts == NONE where the reference
+    returns None."""
+    it = ds.items_struct()
+    if query_items is not None:
+        query_items = np.ascontiguousarray(query_items, np.uint32)
+        nq = len(query_items)
+        qcodes = np.zeros((1, max(1, ds.codes.shape[1])), np.uint8)
+        qheaders = np.zeros((1, ds.headers.shape[1]), np.uint8)
+    else:
+        qcodes = np.ascontiguousarray(qcodes, np.uint8)
+        qheaders = np.ascontiguousarray(qheaders, np.uint8)
+        nq = qcodes.shape[0]
     ids = np.zeros((nq, k), np.uint32)
     dists = np.zeros((nq, k), np.float32)
     counts = np.zeros(nq, np.uint32)
-    it = ds.items_struct()
     rec_item = np.ascontiguousarray(graph.rec_item, np.uint32)
     rec_layer = np.ascontiguousarray(graph.rec_layer, np.uint8)
     offsets = np.ascontiguousarray(graph.offsets, np.uint64)
     nbrs = np.ascontiguousarray(graph.nbrs, np.uint32)
     eps = np.ascontiguousarray(graph.entry_points, np.uint32)
-    rc = lib().orc_search(ds.metric, order, ds.dim, C.byref(it), len(rec_item), _p(rec_item),
-                          _p(rec_layer), _p(offsets), _p(nbrs), _p(eps), len(eps),
-                          int(graph.max_level), nq, _p(qcodes), qcodes.shape[1], _p(qheaders), k,
-                          ef_search, threads, _p(ids), _p(dists), _p(counts))
+    qo = QueryOpts()
+    cand = None
+    if candidates is not None:
+        cand = np.ascontiguousarray(candidates, np.uint32)
+        qo.has_candidates, qo.candidates, qo.n_candidates = 1, cand.ctypes.data, len(cand)
+    qo.query_items = query_items.ctypes.data if query_items is not None else None
+    qo.linear_below, qo.linear_below_ratio = linear_below, linear_below_ratio
+    rc = lib().orc_search_ex(ds.metric, order, ds.dim, C.byref(it), len(rec_item), _p(rec_item),
+                             _p(rec_layer), _p(offsets), _p(nbrs), _p(eps), len(eps),
+                             int(graph.max_level), nq, _p(qcodes), qcodes.shape[1], _p(qheaders), k,
+                             ef_search, threads, C.byref(qo), _p(ids), _p(dists), _p(counts))
     if rc != 0:
         raise RuntimeError(f"orc_search failed: {rc}")
     return ids, dists, counts

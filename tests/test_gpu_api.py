@@ -132,3 +132,285 @@ def test_all_items_are_reachable(H):
     r = db.reader(0)
     res = r.by_vec(np.zeros(dim, np.float32), n=n, ef_search=n)
     assert sorted(i for i, _ in res) == list(range(n))
+
+
+def _rng42(H):
+    """src/tests/mod.rs:145-147: StdRng::from_seed([42; 32]); writer tests use M = M0 = 3 (writer.rs:16-17)"""
+    return H.StdRng.from_seed(bytes([42] * 32))
+
+
+def _rand_index(H, metric, n, dim, m=16, seed=42, index=0, db=None):
+    rng = np.random.default_rng(seed)
+    db = db or H.Database(None, metric)
+    w = db.writer(dim, index=index, m=m, ef=100)
+    vecs = rng.uniform(0, 1, (n, dim)).astype(np.float32)
+    w.add_items(range(n), vecs)
+    w.build()
+    return db, w, vecs, rng
+
+
+def test_clear_small_database(H):
+    """src/tests/writer.rs:21-43: clear() only touches its own index"""
+    db = H.Database(None, H.Metric.COSINE)
+    zero = db.writer(3, index=0)
+    zero.add_item(0, [0.0, 1.0, 2.0])
+    zero.clear()
+    zero.builder().build()
+    one = db.writer(3, index=1)
+    one.add_item(0, [1.0, 2.0, 3.0])
+    one.builder().build()
+    db.writer(3, index=0).clear()
+    assert db.dump(0) == []
+    r = db.reader(1)
+    assert r.item_vector(0).tolist() == [1.0, 2.0, 3.0]
+    r.close()
+
+
+def test_delete_all_but_one_item_and_build(H):
+    """src/tests/writer.rs:47-65 (issue #52)"""
+    db = H.Database(None, H.Metric.COSINE)
+    w = db.writer(3)
+    for i, v in ((1, [1, 2, 0]), (2, [2, 1, 0]), (3, [1, 0, 2]), (0, [0, 1, 2])):
+        w.add_item(i, v)
+    w.builder().build()
+    w = db.writer(3)
+    for i in (0, 2, 3):
+        assert w.del_item(i)
+    w.builder().build()
+    assert db.metadata(0)["items"].tolist() == [1]
+    r = db.reader(0)
+    r.assert_validity()
+    assert [i for i, _ in r.nns(10).by_vector([1, 2, 0]).into_nns()] == [1]
+    r.close()
+
+
+@pytest.mark.parametrize("item", [0xFFFFFFFF, 0xFFFFFFFE])
+def test_use_u32_max_for_a_vec(H, item):
+    """src/tests/writer.rs:67-107"""
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    w = db.writer(3)
+    w.add_item(item, [0.0, 1.0, 2.0])
+    w.builder(_rng42(H)).build(3, 3)
+    m = db.metadata(0)
+    assert m["items"].tolist() == [item] and m["entry_points"].tolist() == [item] and m["max_level"] == 1
+    assert _dump_links(db) == [[item, 0, []], [item, 1, []]]
+
+
+def test_write_multiple_and_random_indexes(H):
+    """src/tests/writer.rs:157-228: several indexes in one database do not interfere"""
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    for i in range(5):
+        w = db.writer(3, index=i)
+        w.add_item(0, [0.0, 1.0, 2.0])
+        w.builder(_rng42(H)).build(3, 3)
+    for i in range(5):
+        m = db.metadata(i)
+        assert (m["dimensions"], m["items"].tolist(), m["entry_points"].tolist(), m["max_level"]) == (3, [0], [0], 1)
+        assert _dump_links(db, i) == [[0, 0, []], [0, 1, []]]
+    rng = np.random.default_rng(42)
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    for index in rng.permutation(10):
+        w = db.writer(10, index=int(index))
+        for i in range(10):
+            w.add_item(i, rng.random(10, dtype=np.float32))
+        w.builder().build()
+    for index in range(10):
+        r = db.reader(index)
+        r.assert_validity()
+        assert r.n_items() == 10
+        r.close()
+
+
+@pytest.mark.parametrize("metric", ["EUCLIDEAN", "COSINE"])
+def test_delete_one_item_in_a_one_item_db(H, metric):
+    """src/tests/writer.rs:441-480, 550-586: the index becomes empty (metadata stays, no links)"""
+    db = H.Database(None, getattr(H.Metric, metric))
+    rng = _rng42(H)
+    w = db.writer(2)
+    w.add_item(0, [0.0, 0.0])
+    w.builder(rng).build(3, 3)
+    m = db.metadata(0)
+    assert (m["items"].tolist(), m["entry_points"].tolist(), m["max_level"]) == ([0], [0], 1)
+    assert _dump_links(db) == [[0, 0, []], [0, 1, []]]
+    w = db.writer(2)
+    assert w.del_item(0)
+    w.builder(rng).build(3, 3)
+    m = db.metadata(0)
+    assert (m["items"].tolist(), m["entry_points"].tolist(), m["max_level"]) == ([], [], 0)
+    assert len(db.dump(0)) == 2  # metadata + version
+    r = db.reader(0)
+    assert r.item_vector(0) is None
+    r.close()
+
+
+def test_delete_document_in_an_empty_index_74(H):
+    """src/tests/writer.rs:482-548"""
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    rng = _rng42(H)
+    w = db.writer(2)
+    assert not w.del_item(0)
+    w.add_item(0, [0.0, 0.0])
+    w.builder(rng).build(3, 3)
+    assert _dump_links(db) == [[0, 0, []], [0, 1, []]]
+    w1, w2 = db.writer(2, index=0), db.writer(2, index=1)
+    assert w1.del_item(0)
+    assert not w2.del_item(0)
+    w1.builder(rng).build(3, 3)
+    w2.builder(rng).build(3, 3)
+    for index in (0, 1):
+        m = db.metadata(index)
+        assert (m["items"].tolist(), m["entry_points"].tolist(), m["max_level"]) == ([], [], 0)
+    r = db.reader(1)
+    s = r.nns(10).by_vector([0.0, 0.0])
+    assert s.into_nns() == [] and not s.did_cancel()
+    r.close()
+
+
+def test_delete_one_item_no_snapshots(H):
+    """src/tests/writer.rs:680-730"""
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    w = db.writer(2)
+    for i in range(6):
+        w.add_item(i, [float(i), 0.0])
+    w.builder().build(3, 3)
+    for gone in (3, 1):
+        w = db.writer(2)
+        assert w.del_item(gone)
+        w.builder().build(3, 3)
+    assert not db.writer(2).contains_item(3) and not db.writer(2).contains_item(1)
+    assert not ({1, 3} & {i for i, _, _ in _dump_links(db)})
+    r = db.reader(0)
+    r.assert_validity()
+    r.close()
+
+
+def test_force_rebuild_and_search(H):
+    """src/tests/writer.rs:749-775 + search_by_item tests (src/tests/reader.rs:113-143)"""
+    db, w, vecs, rng = _rand_index(H, H.Metric.COSINE, 100, 768)
+    before = _dump_links(db)
+    db.writer(768).builder().force_rebuild()
+    assert sorted({i for i, l, _ in _dump_links(db) if l == 0}) == list(range(100))
+    assert not db.writer(768).need_build()
+    r = db.reader(0)
+    r.assert_validity()
+    found = r.nns(10).by_item(0).into_nns()
+    assert len(found) == 10 and 0 not in [i for i, _ in found]
+    assert r.nns(10).by_item(101) is None
+    # search_cancellation_works (src/tests/reader.rs:145-170)
+    q = rng.random(768, dtype=np.float32)
+    assert not r.nns(10).by_vector_with_cancellation(q, lambda: False).did_cancel()
+    assert r.nns(10).by_vector_with_cancellation(q, lambda: True).did_cancel()
+    assert not r.nns(10).by_item_with_cancellation(0, lambda: False).did_cancel()
+    assert r.nns(10).by_item_with_cancellation(0, lambda: True).did_cancel()
+    r.close()
+    assert before  # the first build had links too
+
+
+def test_search_on_candidates_has_right_num(H):
+    """src/tests/reader.rs:41-78, several indexes in one database"""
+    db = H.Database(None, H.Metric.COSINE)
+    for index in range(1, 4):
+        _rand_index(H, H.Metric.COSINE, 1000, 768, seed=index, index=index, db=db)
+    rng = np.random.default_rng(0)
+    for index in rng.permutation([1, 2, 3]):
+        r = db.reader(int(index))
+        q = rng.random(768, dtype=np.float32)
+        cand = np.unique(rng.integers(0, 1000, 10)).astype(np.uint32)
+        found = r.nns(10).candidates(cand).by_vector(q).into_nns()
+        assert sorted(i for i, _ in found) == cand.tolist()
+        one = rng.integers(0, 1000, 1).astype(np.uint32)
+        found = r.nns(1).candidates(one).by_vector(q).into_nns()
+        assert [i for i, _ in found] == one.tolist()
+        r.close()
+
+
+def test_quantized_iter_has_right_dimensions(H):
+    """src/tests/reader.rs:17-38 (issue #78): a prime number of dimensions, binary quantized"""
+    dim = 1063
+    db = H.Database(None, H.Metric.BQ_COSINE)
+    w = db.writer(dim)
+    v = np.random.default_rng(42).random(dim, dtype=np.float32) - 0.5
+    w.add_item(0, v)
+    w.builder().build()
+    r = db.reader(0)
+    (_, new_vec), = list(r.iter())
+    assert len(new_vec) == dim
+    assert np.array_equal(new_vec, np.where(np.signbit(v), -1.0, 1.0).astype(np.float32))
+    r.close()
+
+
+def test_need_build_and_reader_open_errors(H):
+    """writer.rs:423-436, reader.rs:387-417"""
+    from hannoy_amd.api import MissingMetadata, NeedBuild, UnmatchingDistance
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    w = db.writer(4)
+    assert w.is_empty() and w.need_build()
+    with pytest.raises(MissingMetadata):
+        db.reader(0)
+    w.add_items(range(20), np.random.default_rng(1).random((20, 4), dtype=np.float32))
+    assert not w.is_empty() and w.need_build()
+    w.builder().ef_construction(32).alpha(1.0).build()
+    assert not w.need_build()
+    w.add_item(99, [1, 2, 3, 4])
+    assert w.need_build()
+    with pytest.raises(NeedBuild):
+        db.reader(0)
+    w.builder().build()
+    r = db.reader(0)
+    assert r.n_items() == 21 and r.dimensions == 4 and r.version() == (0, 1, 3) and r.n_entrypoints() >= 1
+    assert r.contains_item(99) and not r.contains_item(98) and not r.is_empty()
+    assert r.item_vector(99).tolist() == [1, 2, 3, 4]
+    r.close()
+    db.distance = H.Metric.COSINE
+    with pytest.raises(UnmatchingDistance):
+        db.reader(0)
+
+
+def test_prepare_changing_distance(H):
+    """writer.rs:358-410: cosine -> binary quantized cosine keeps links and metadata, every item is
+    re-encoded and marked updated; cosine -> euclidean drops links + metadata"""
+    from hannoy_amd.api import MODE_ITEM, MODE_UPDATED, key
+    db, w, vecs, rng = _rand_index(H, H.Metric.COSINE, 300, 70)
+    vecs = vecs - 0.5
+    w.add_items(range(300), vecs)
+    w.builder().build()
+    links_before = _dump_links(db)
+    w2 = db.writer(70).prepare_changing_distance(H.Metric.BQ_COSINE)
+    assert db.distance == H.Metric.BQ_COSINE and w2.need_build()
+    assert _dump_links(db) == links_before and db.metadata(0) is not None
+    assert all(key(0, MODE_UPDATED, i) in db.kv for i in range(300))
+    v = db.kv[key(0, MODE_ITEM, 7)]
+    assert len(v) == 1 + 4 + 16  # tag + norm header + 128 bits
+    bits = np.unpackbits(np.frombuffer(v, np.uint8, offset=5), bitorder="little")[:70]
+    assert np.array_equal(bits, (~np.signbit(vecs[7])).astype(np.uint8))
+    w2.builder().build()
+    r = db.reader(0)
+    r.assert_validity()
+    assert r.nns(1).by_item(7) is not None
+    r.close()
+    # a different family: links and metadata are dropped, the next build starts from scratch
+    db, w, vecs, rng = _rand_index(H, H.Metric.COSINE, 200, 16)
+    w3 = db.writer(16).prepare_changing_distance(H.Metric.EUCLIDEAN)
+    assert _dump_links(db) == [] and db.metadata(0) is None
+    w3.builder().build()
+    r = db.reader(0)
+    r.assert_validity()
+    got = r.nns(1).by_vector(vecs[5]).into_nns()
+    assert got[0][0] == 5 and got[0][1] == 0.0
+    r.close()
+
+
+def test_build_cancel_and_progress(H):
+    """writer.rs:97-131: cancel -> BuildCancelled, progress reports inserted items"""
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    w = db.writer(8)
+    w.add_items(range(500), np.random.default_rng(3).random((500, 8), dtype=np.float32))
+    with pytest.raises(H.BuildCancelled):
+        w.builder().cancel(lambda: True).build()
+    w.add_item(0, np.zeros(8, np.float32))  # the cancelled build consumed the `updated` stones
+    seen = []
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    w = db.writer(8)
+    w.add_items(range(500), np.random.default_rng(3).random((500, 8), dtype=np.float32))
+    w.builder().progress(lambda done, total: seen.append((done, total))).build()
+    assert seen and seen[-1] == (500, 500)
