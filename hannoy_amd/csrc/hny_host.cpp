@@ -266,6 +266,7 @@ struct hny_builder {
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
   int stage_rows = 0;      // selected rows staged in LDS by the workgroup prune kernels
+  int prune_nw = 4;        // candidates per chunk (= waves per workgroup) of k_prune_wg
   bool wave_prune_only = false;
   size_t max_ops = 0, sel_words = 0;
   double t_upload = 0, t_build0 = 0, t_build = 0;
@@ -772,6 +773,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     // the workgroup prune kernels carry their own wave-order arithmetic: strict mode and very long
     // rows use the single-wave kernels, which all go through dist_rows
     b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0 || b->shape.nch > 8 || o.x86_order;
+    b->prune_nw = env_int("HNY_PRUNE_NW", 4) == 8 ? 8 : 4;
   }
 
   // ---- device memory ----
@@ -1019,7 +1021,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   auto launch_prune = [&](const PruneArgs &p, hipStream_t st) -> hipError_t {
     if (b->wave_prune_only)
       return hnyk_prune(b->g, p, b->shape, (int)std::min<uint32_t>(p.hi - p.lo, b->walk_slots), st);
-    return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
+    return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, b->prune_nw, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
   };
   u32 *queues = b->d_nseg.p + 4; // 8 work counters
   HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));

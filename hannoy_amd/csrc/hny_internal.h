@@ -180,7 +180,7 @@ hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, i
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st);
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st);
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);
-hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid,
+hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st);
 hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
                          hipStream_t st);

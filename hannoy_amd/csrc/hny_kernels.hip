@@ -1400,25 +1400,25 @@ struct WgPruneLds {
   u64 *S;          // [HNY_MAX_CAP] selected keys
   u32 *s_ids;      // [HNY_MAX_CAP]
   float *s_norm;   // [HNY_MAX_CAP]
-  int *surv;       // [4] chunk member survived the test against S
-  u32 *vmask;      // [4] bit j: chunk member violates against chunk member j
-  float *cnorm;    // [4]
-  unsigned char *cbuf;  // [4][row_stride] the chunk's candidate rows
+  int *surv;       // [8] chunk member survived the test against S
+  u32 *vmask;      // [8] bit j: chunk member violates against chunk member j
+  float *cnorm;    // [8]
+  unsigned char *cbuf;  // [NW][row_stride] the chunk's candidate rows
   unsigned char *stage; // [SL][row_stride] selected rows
   int SL;          // staged rows (multiple of 64/LPR)
 };
 
-// robust_prune for a 4-wave workgroup.  `exists i in S: bits(d(c,i)*alpha) < bits(dq)` does not
-// depend on the order in which S is scanned, so 4 consecutive candidates are tested concurrently,
-// one per wave, against the selected set as it stood before the chunk (rows from LDS, early exit);
-// the survivors are then tested against each other (rows exchanged through LDS) and the chunk is
-// resolved in candidate order — exactly the sequential outcome, with 3 barriers per 4 candidates.
-// Each wave streams its next candidate row from HBM one chunk ahead.
-template <int LPR, int NCH>
+// robust_prune for an NW-wave workgroup (NW = 4 or 8).  `exists i in S: bits(d(c,i)*alpha) <
+// bits(dq)` does not depend on the order in which S is scanned, so NW consecutive candidates are
+// tested concurrently, one per wave, against the selected set as it stood before the chunk (rows
+// from LDS, early exit); the survivors are then tested against each other (rows exchanged through
+// LDS) and the chunk is resolved in candidate order — exactly the sequential outcome, with 3
+// barriers per NW candidates.  Each wave streams its next candidate row from HBM one chunk ahead.
+template <int LPR, int NCH, int NW>
 __device__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, const WgPruneLds &L,
                         u64 &evals) {
   constexpr int RPG = 64 / LPR;
-  constexpr int NW = 4;
+  static_assert(NW == 4 || NW == 8, "chunk of 4 or 8 candidates");
   const int tid = threadIdx.x, w = tid >> 6, ln = tid & 63, t = ln % LPR, sub = ln / LPR;
   const int j4 = fold4_row<LPR>();
   int s_len = 0;
@@ -1502,30 +1502,36 @@ __device__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, cons
       L.cnorm[w] = cn;
     }
     __syncthreads();
-    // C: survivors against the earlier members of the chunk (one folded pass over cbuf[0..3])
+    // C: survivors against the earlier members of the chunk (folded passes over cbuf, 4 rows each)
     u32 vm = 0;
     if (surv && w > 0) {
-      float4 r[4][NCH];
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        load_row_lds<LPR, NCH>(L.cbuf + (size_t)j * g.row_stride, t, g.n16, r[j]);
-      const float rn = L.cnorm[j4];
-      float d;
-      if (g.mclass == MC_BIN)
-        d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
-                                            partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
-                         cn, rn);
-      else
-        d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
-                                              partial_f32<NCH>(g.mclass, c, r[1]),
-                                              partial_f32<NCH>(g.mclass, c, r[2]),
-                                              partial_f32<NCH>(g.mclass, c, r[3])),
-                         cn, rn);
-      const float da = d * g.alpha;
-      const bool hit = sub == 0 && j4 < w && L.surv[j4] != 0 && fbits(da) < cdb;
+      for (int q4 = 0; q4 < NW / 4; q4++) {
+        if (q4 * 4 < w) { // wave-uniform
+          float4 r[4][NCH];
 #pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << j;
+          for (int j = 0; j < 4; j++)
+            load_row_lds<LPR, NCH>(L.cbuf + (size_t)(q4 * 4 + j) * g.row_stride, t, g.n16, r[j]);
+          const int jm = q4 * 4 + j4;
+          const float rn = L.cnorm[jm];
+          float d;
+          if (g.mclass == MC_BIN)
+            d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
+                                                partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
+                             cn, rn);
+          else
+            d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
+                                                  partial_f32<NCH>(g.mclass, c, r[1]),
+                                                  partial_f32<NCH>(g.mclass, c, r[2]),
+                                                  partial_f32<NCH>(g.mclass, c, r[3])),
+                             cn, rn);
+          const float da = d * g.alpha;
+          const bool hit = sub == 0 && jm < w && L.surv[jm] != 0 && fbits(da) < cdb;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << (q4 * 4 + j);
+        }
+      }
       if (ln == 0) evals += (u64)w;
     }
     if (ln == 0) L.vmask[w] = vm;
@@ -1562,29 +1568,29 @@ __device__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, cons
   return s_len;
 }
 
-__host__ __device__ inline size_t wg_prune_lds_bytes(u32 rcap, u32 row_stride, int SL) {
-  return (size_t)rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4) + 64 + (size_t)(SL + 4) * row_stride;
+__host__ __device__ inline size_t wg_prune_lds_bytes(u32 rcap, u32 row_stride, int SL, int NW) {
+  return (size_t)rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4) + 96 + (size_t)(SL + NW) * row_stride;
 }
 
-__device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL, u32 row_stride) {
+__device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL, u32 row_stride, int NW) {
   WgPruneLds L;
   L.S = reinterpret_cast<u64 *>(base);
   L.s_ids = reinterpret_cast<u32 *>(L.S + HNY_MAX_CAP);
   L.s_norm = reinterpret_cast<float *>(L.s_ids + HNY_MAX_CAP);
   L.surv = reinterpret_cast<int *>(L.s_norm + HNY_MAX_CAP);
-  L.vmask = reinterpret_cast<u32 *>(L.surv + 4);
-  L.cnorm = reinterpret_cast<float *>(L.vmask + 4);
+  L.vmask = reinterpret_cast<u32 *>(L.surv + 8);
+  L.cnorm = reinterpret_cast<float *>(L.vmask + 8);
   L.cbuf = reinterpret_cast<unsigned char *>(L.cnorm + 8);
-  L.stage = L.cbuf + 4 * (size_t)row_stride;
+  L.stage = L.cbuf + (size_t)NW * row_stride;
   L.SL = SL;
   return L;
 }
 
-template <int LPR, int NCH>
-__global__ __launch_bounds__(256) void k_prune_wg(GraphDev g, PruneArgs a, int SL) {
+template <int LPR, int NCH, int NW>
+__global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g, PruneArgs a, int SL) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *list = reinterpret_cast<u64 *>(smem);
-  WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride);
+  WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride, NW);
   const int tid = threadIdx.x;
   u64 evals = 0;
   for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
@@ -1592,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_prune_wg(GraphDev g, PruneArgs a, int S
     const int n = (int)a.cand_n[m];
     for (int e = tid; e < n; e += blockDim.x) list[e] = a.cand[(size_t)m * a.rcap + e];
     __syncthreads();
-    const int s_len = wg_prune<LPR, NCH>(g, list, n, (int)a.cap, L, evals);
+    const int s_len = wg_prune<LPR, NCH, NW>(g, list, n, (int)a.cap, L, evals);
     u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
     if (tid == 0) out[0] = (u64)s_len;
     if (tid < s_len) out[1 + tid] = L.S[tid];
@@ -1736,7 +1742,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int S
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *lk = reinterpret_cast<u64 *>(smem);          // [HNY_MAX_CAP] the node's list
   u64 *sorted = lk + HNY_MAX_CAP;                   // [HNY_MAX_CAP]
-  WgPruneLds L = wg_prune_carve(smem + (size_t)2 * HNY_MAX_CAP * 8, SL, g.row_stride);
+  WgPruneLds L = wg_prune_carve(smem + (size_t)2 * HNY_MAX_CAP * 8, SL, g.row_stride, 4);
   const int tid = threadIdx.x;
   const u32 n_def = *a.n_deferred;
   u64 evals = 0;
@@ -1784,7 +1790,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int S
           sorted[rk] = mine;
         }
         __syncthreads();
-        const int s_len = wg_prune<LPR, NCH>(g, sorted, cnt, (int)cap, L, evals);
+        const int s_len = wg_prune<LPR, NCH, 4>(g, sorted, cnt, (int)cap, L, evals);
         if (tid < s_len) lk[tid] = L.S[tid];
         cnt = s_len;
         frozen = (s_len == (int)cap);
@@ -2128,12 +2134,15 @@ struct PruneLauncher {
 };
 template <int L, int C>
 struct PruneWgLauncher {
-  static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int grid, hipStream_t st) {
+  static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int nw, int grid, hipStream_t st) {
     if constexpr (C > 8) {
       return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
     } else {
-      size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL);
-      hipLaunchKernelGGL((k_prune_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
+      size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL, nw);
+      if (nw == 8)
+        hipLaunchKernelGGL((k_prune_wg<L, C, 8>), dim3(grid), dim3(512), lds, st, g, a, SL);
+      else
+        hipLaunchKernelGGL((k_prune_wg<L, C, 4>), dim3(grid), dim3(256), lds, st, g, a, SL);
       return hipGetLastError();
     }
   }
@@ -2144,7 +2153,7 @@ struct ApplyWgLauncher {
     if constexpr (C > 8) {
       return hipErrorInvalidValue;
     } else {
-      size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL);
+      size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL, 4);
       hipLaunchKernelGGL((k_apply_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
       return hipGetLastError();
     }
@@ -2198,9 +2207,9 @@ hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int 
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<ApplyLauncher>(s, g, a, grid, st);
 }
-hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid,
+hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st) {
-  return dispatch_shape<PruneWgLauncher>(s, g, a, SL, grid, st);
+  return dispatch_shape<PruneWgLauncher>(s, g, a, SL, nw, grid, st);
 }
 hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
                          hipStream_t st) {
