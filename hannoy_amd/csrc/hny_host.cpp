@@ -267,6 +267,7 @@ struct hny_builder {
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
   int stage_rows = 0;      // selected rows staged in LDS by the workgroup prune kernels
   int prune_nw = 4;        // candidates per chunk (= waves per workgroup) of k_prune_wg
+  int vis_slots_env = -1;  // HNY_VIS_SLOTS: LDS visited table entries per walk wave, -1 = auto
   bool wave_prune_only = false;
   size_t max_ops = 0, sel_words = 0;
   double t_upload = 0, t_build0 = 0, t_build = 0;
@@ -292,6 +293,17 @@ struct hny_builder {
   }
 };
 enum { EV_WALK = 0, EV_PRUNE = 1, EV_SORT = 2, EV_APPLY = 3, EV_KINDS = 4 };
+// LDS visited table of a walk wave: what is left of a 10 KB share (16 waves per CU in 160 KB) after
+// the beam, in whole 64-entry rows
+static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
+  if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
+  // measured: +5 % on 3 KB rows (C2/C3), -3 % on 512-B rows (the table clear per greedy layer and
+  // the longer probes outweigh the saved L2 atomics when a row costs little): rows >= 1 KB only
+  if ((size_t)b->g.n16 * 16 < 1024) return 0;
+  const size_t fixed = hnyk_walk_lds_bytes(rcap);
+  if (fixed + 512 * 4 > 10240) return 512;
+  return (uint32_t)((10240 - fixed) / 4 / 64 * 64);
+}
 static void prof_begin(hny_builder *b, int kind, hipStream_t st = nullptr) {
   if (!b->profiling) return;
   if (!st) st = b->stream;
@@ -764,6 +776,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   b->walk_slots = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_WALK_SLOTS", 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
+  b->vis_slots_env = env_int("HNY_VIS_SLOTS", -1);
   {
     // LDS staging budget of the workgroup prune, whole load groups
     int rpg = 64 / b->shape.lpr;
@@ -999,6 +1012,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
+    w.vis_slots = vis_slots_for(b, w.rcap);
     w.queue = queue;
     return w;
   };
@@ -1480,6 +1494,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
+    w.vis_slots = vis_slots_for(b, w.rcap);
     w.queue = queues;
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
@@ -1670,6 +1685,7 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     a.bits_words = b->bits_words;
     a.vlog = b->d_vlog.p;
     a.log_cap = b->log_cap;
+    a.vis_slots = vis_slots_for(b, a.rcap);
     a.queue = queues;
     a.status = dstatus.p;
     a.cand_slots = dcslots.p;

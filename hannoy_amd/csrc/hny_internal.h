@@ -102,6 +102,7 @@ struct WalkArgs {
   const u64 *perm;
   u32 knn_k;        // reader mode: wanted hits (exhaustive fallback below that, reader.rs:771-795)
   u32 knn_ef;       // reader mode: opt.ef of the query builder
+  u32 vis_slots;    // LDS visited table entries per wave (0: HBM bitset only)
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -129,6 +130,7 @@ struct NnsArgs {
   u64 *heap;                   // [grid][heap_cap]
   u32 heap_cap;
   u32 *queue;
+  u32 vis_slots;               // LDS visited table entries per wave
   u32 *status;                 // [n_queries] 1 = the heap overflowed: run again with a larger one
   // brute_force_search (reader.rs:667-711): the existing candidates, ascending
   const u32 *cand_slots;

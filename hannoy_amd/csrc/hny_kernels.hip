@@ -545,12 +545,40 @@ __device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
   beam_evicted(s, oldmax, nd);
 }
 
+// visited set of one query (RoaringBitmap `visited`, hnsw.rs:471 / `path`, reader.rs:726).  First
+// level: an open-addressing hash table in LDS (a query marks ~1e3 of the N items, so a per-wave
+// N-bit set in HBM costs one scattered L2 atomic per neighbour looked at and a dirty 128-B line per
+// visited item — ≈10 % of k_walk's traffic at C2 — while the table costs an LDS compare-and-swap).
+// Second level: the per-wave HBM bitset + log, used only once the table is 3/4 full (`spill`) and by
+// the Reader's exhaustive fallback, which scans for unvisited items (visited_flush).
 struct Visited {
   u32 *bits;
   u32 *vlog;
   u32 bits_words, log_cap, log_len;
   bool log_over;
+  u32 *tab;       // LDS, `slots` entries, HNY_SENT = empty; null: bitset only
+  u32 slots, count, limit;
+  bool spill;     // the table is closed for insertion: new ids go to the bitset
+  bool in_bits;   // the last visited_insert went to the bitset (its new ids must be logged)
 };
+
+__device__ __forceinline__ void visited_init(Visited &v, u32 *bits, u32 bits_words, u32 *vlog, u32 log_cap,
+                                             u32 *tab, u32 slots) {
+  v.bits = bits;
+  v.vlog = vlog;
+  v.bits_words = bits_words;
+  v.log_cap = log_cap;
+  v.log_len = 0;
+  v.log_over = false;
+  v.tab = slots ? tab : nullptr;
+  v.slots = slots;
+  v.count = 0;
+  v.limit = slots > 256u ? slots / 4u * 3u - 64u : 0u;
+  v.spill = slots <= 256u;
+  v.in_bits = v.tab == nullptr;
+  for (u32 i = threadIdx.x; i < slots; i += 64) tab[i] = HNY_SENT;
+  WSYNC();
+}
 
 __device__ __forceinline__ void visited_clear(Visited &v) {
   const int ln = threadIdx.x;
@@ -561,13 +589,44 @@ __device__ __forceinline__ void visited_clear(Visited &v) {
   }
   v.log_len = 0;
   v.log_over = false;
+  if (v.tab) {
+    for (u32 i = ln; i < v.slots; i += 64) v.tab[i] = HNY_SENT;
+    v.count = 0;
+    v.spill = v.slots <= 256u;
+  }
   WSYNC();
 }
 
-// mark ids (one per lane, `valid` lanes) visited; returns whether this lane's id was new.
+// mark ids (one per lane, `valid` lanes) visited; returns whether this lane's id was new.  Two lanes
+// holding the same id: exactly one of them is told "new" (CAS / atomicOr decide which).
 __device__ __forceinline__ bool visited_insert(Visited &v, u32 id, bool valid) {
-  bool isnew = false;
-  if (valid) {
+  bool isnew = false, found = false;
+  if (v.tab) {
+    const bool ins = !v.spill; // wave-uniform
+    if (valid) {
+      u32 h = (u32)(((u64)(id * 0x9E3779B1u) * (u64)v.slots) >> 32);
+      for (;;) {
+        const u32 cur = ins ? atomicCAS(&v.tab[h], HNY_SENT, id) : v.tab[h];
+        if (cur == HNY_SENT) {
+          isnew = ins;
+          break;
+        }
+        if (cur == id) {
+          found = true;
+          break;
+        }
+        h = h + 1u == v.slots ? 0u : h + 1u;
+      }
+    }
+    if (ins) {
+      v.count += (u32)__popcll(__ballot(isnew));
+      if (v.count > v.limit) v.spill = true;
+      v.in_bits = false;
+      return isnew;
+    }
+  }
+  v.in_bits = true;
+  if (valid && !found) {
     u32 b = 1u << (id & 31);
     u32 old = atomicOr(&v.bits[id >> 5], b);
     isnew = !(old & b);
@@ -576,6 +635,7 @@ __device__ __forceinline__ bool visited_insert(Visited &v, u32 id, bool valid) {
 }
 
 __device__ __forceinline__ void visited_log(Visited &v, u32 id, bool isnew, u64 nmask, int rank) {
+  if (!v.in_bits) return; // table entries are cleared with the table
   int n_new = __popcll(nmask);
   if (v.log_len + n_new <= v.log_cap) {
     if (isnew) v.vlog[v.log_len + rank] = id;
@@ -585,9 +645,23 @@ __device__ __forceinline__ void visited_log(Visited &v, u32 id, bool isnew, u64 
   v.log_len += n_new;
 }
 
+// copy the table into the bitset so that the bitset alone answers "visited?" (the Reader's
+// exhaustive fallback scans it word by word); later ids go to the bitset
+__device__ __forceinline__ void visited_flush(Visited &v) {
+  if (!v.tab) return;
+  for (u32 i = threadIdx.x; i < v.slots; i += 64) {
+    const u32 id = v.tab[i];
+    if (id != HNY_SENT) atomicOr(&v.bits[id >> 5], 1u << (id & 31));
+  }
+  if (v.count) v.log_over = true; // not logged: clear the whole bitset afterwards
+  v.spill = true;
+  __threadfence_block();
+  WSYNC();
+}
+
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
 template <int LPR, int NCH>
-__device__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
+__device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
                                const unsigned char *qrow) {
@@ -782,12 +856,8 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
   s.tie_bits = 0;
   s.dropped = false;
   Visited vis;
-  vis.bits = a.bits + (size_t)blockIdx.x * a.bits_words;
-  vis.vlog = a.vlog + (size_t)blockIdx.x * a.log_cap;
-  vis.bits_words = a.bits_words;
-  vis.log_cap = a.log_cap;
-  vis.log_len = 0;
-  vis.log_over = false;
+  visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
+               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + HNY_MAX_EPS, a.vis_slots);
   u64 evals = 0;
   u32 err_iter = 0, log_over_cnt = 0;
 
@@ -870,6 +940,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
       // sharing the visited set, until opt.ef hits are collected.  Rare; written for clarity.
       const u32 nwords = (g.n + 31) >> 5;
       u32 pos = 0;
+      visited_flush(vis);
       while (pos < g.n) {
         const u32 wbase = pos >> 5;
         const u32 widx = wbase + (u32)ln;
@@ -1127,12 +1198,8 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
   s.tie_bits = 0;
   s.dropped = false;
   Visited vis;
-  vis.bits = a.bits + (size_t)blockIdx.x * a.bits_words;
-  vis.vlog = a.vlog + (size_t)blockIdx.x * a.log_cap;
-  vis.bits_words = a.bits_words;
-  vis.log_cap = a.log_cap;
-  vis.log_len = 0;
-  vis.log_over = false;
+  visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
+               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + HNY_MAX_EPS, a.vis_slots);
   QHeap Q;
   Q.h = a.heap + (size_t)blockIdx.x * a.heap_cap;
   Q.cap = a.heap_cap;
@@ -1194,6 +1261,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
         const u32 nwords = (g.n + 31) >> 5;
         const int stop = a.by_item ? (int)a.k : (int)a.ef_opt;
         u32 pos = 0;
+        visited_flush(vis);
         while (pos < g.n) {
           const u32 wbase = pos >> 5;
           const u32 widx = wbase + (u32)ln;
@@ -2103,7 +2171,7 @@ hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
 template <int L, int C>
 struct WalkLauncher {
   static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
-    size_t lds = hnyk_walk_lds_bytes(a.rcap);
+    size_t lds = hnyk_walk_lds_bytes(a.rcap) + (size_t)a.vis_slots * 4;
     hipLaunchKernelGGL((k_walk<L, C>), dim3(grid), dim3(64), lds, st, g, a);
     return hipGetLastError();
   }
@@ -2111,7 +2179,7 @@ struct WalkLauncher {
 template <int L, int C>
 struct NnsFilteredLauncher {
   static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
-    size_t lds = hnyk_walk_lds_bytes(a.rcap);
+    size_t lds = hnyk_walk_lds_bytes(a.rcap) + (size_t)a.vis_slots * 4;
     hipLaunchKernelGGL((k_nns_filtered<L, C>), dim3(grid), dim3(64), lds, st, g, a);
     return hipGetLastError();
   }

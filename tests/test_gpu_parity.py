@@ -477,3 +477,41 @@ def test_locality_ordered_batches_equal_oracle(orc, hny, metric, dim):
         g2 = b.finish()
     assert big >= 1
     _same_graph(g2, o)
+
+
+@pytest.mark.parametrize("slots", ["0", "320", "512", "4096"])
+def test_lds_visited_table_and_spill_equal_oracle(orc, hny, slots, monkeypatch):
+    """The visited set is an LDS hash table that spills into the HBM bitset once 3/4 full
+    (HNY_VIS_SLOTS forces its size; 320 spills after 176 items, 0 = bitset only): builds, k-NN search,
+    the Reader's exhaustive fallback (table flushed into the bitset) and the filtered search must not
+    depend on it."""
+    monkeypatch.setenv("HNY_VIS_SLOTS", slots)
+    rng = np.random.default_rng(77)
+    n, dim, M, M0, ef = 3000, 64, 8, 16, 64
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    vecs[rng.integers(0, n, 40)] = 0.0  # zero vectors: distance 0 to everything -> ties, fallback
+    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, M, seed=3))
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=0.2, batch_max=256)
+    qs = rng.uniform(-1, 1, (300, dim)).astype(np.float32)
+    qs[:5] = 0.0
+    qc = orc.encode_vectors(0, qs)
+    qh = orc.make_headers(0, dim, qc)
+    with hny.Builder(items, M=M, M0=M0, ef_construction=ef, batch_frac=0.2, batch_max=256) as b:
+        b.run()
+        g = b.finish()
+        got = b.search_knn(qc, qh, k=10, ef_search=300)
+        cand = ds.ids[rng.random(n) < 0.02]
+        gotf = b.nns(qc, qh, k=10, ef_search=300, candidates=cand, linear_below=0)
+        goti = b.nns(k=10, ef_search=20, query_items=ds.ids[:200])
+    assert g.n_tie_pool_overflow == 0
+    _same_graph(g, o)
+    for got_, kw in ((got, {}), (gotf, dict(candidates=cand, linear_below=0)),
+                     (goti, dict(query_items=ds.ids[:200]))):
+        ef_s = 20 if "query_items" in kw else 300
+        qq = (None, None) if "query_items" in kw else (qc, qh)
+        want = orc.search(ds, g, qq[0], qq[1], k=10, ef_search=ef_s, order=orc.ORDER_WAVE, threads=8, **kw)
+        assert np.array_equal(got_[2], want[2])
+        for r in range(len(want[2])):
+            c = int(want[2][r])
+            assert np.array_equal(got_[0][r, :c], want[0][r, :c])
+            assert np.array_equal(got_[1][r, :c].view(np.uint32), want[1][r, :c].view(np.uint32))
