@@ -168,7 +168,9 @@ def main():
         graph = step()
     value = a.n * a.steps / dt if a.steps else 0.0
 
-    # ---- roofline of the dominant kernel (k_walk): algorithmic bytes / device time ----
+    # ---- roofline of the dominant kernel (k_walk): algorithmic bytes / device time, HIP events on
+    # the builder's stream around every k_walk dispatch (a level-0 batch: descent dispatch + key sort +
+    # layer-0 dispatch under one pair); `launches` = k_walk dispatches, what rocprofv3 counts ----
     walk_bytes = graph.n_evals_walk * bytes_per_eval
     roof = None
     if graph.t_walk_kernels_s > 0:
@@ -183,7 +185,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
     # the figure comes from the committed rocprofv3 --pmc passes of this same command
     # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch
-    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_tuned.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_final.json")
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
                   and world == 1 and not a.x86_order)
@@ -192,13 +194,12 @@ def main():
             pk = json.load(f).get("k_walk")
         if pk:
             total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
-            roof["traffic"] = int(total / max(1, graph.n_walk_launches))
-            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_tuned.json: rocprofv3 --pmc FETCH_SIZE / "
-                                      "WRITE_SIZE passes of this command, 2x FETCH + WRITE summed over "
-                                      f"the {pk['launches']} k_walk dispatches of one build, divided by the "
-                                      "timed launches (a level-0 batch = descent + key sort + layer-0 "
-                                      "walk under one HIP-event pair); FETCH_SIZE counts Infinity-Cache "
-                                      "hits too, so this is L2-to-fabric traffic, an upper bound on HBM")
+            roof["traffic"] = int(total / max(1, pk["launches"]))
+            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_final.json: rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command (scripts/profile_c2.sh), 2x FETCH + "
+                                      f"WRITE summed over the {pk['launches']} k_walk dispatches of one build, "
+                                      "per dispatch; FETCH_SIZE counts Infinity-Cache hits too, so this is "
+                                      "L2-to-fabric traffic, an upper bound on HBM")
 
     out = {
         "metric": "vectors indexed/sec (build) + recall@10, 1M x 768 Cosine M=16 efC=100",

@@ -279,6 +279,7 @@ struct hny_builder {
   std::vector<Ev> evs;
   size_t ev_used = 0;
   bool profiling = false;
+  uint64_t n_walk_dispatch = 0; // k_walk launches since the last reset
   ~hny_builder() {
     for (auto &e : sync_evs) (void)hipEventDestroy(e);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -400,6 +401,7 @@ int reset_graph(hny_builder *b) {
   b->in_batch = false;
   b->finalized = false;
   b->ev_used = 0;
+  b->n_walk_dispatch = 0;
   b->sync_used = 0;
   b->t_build0 = now_s();
   return HNY_OK;
@@ -1054,7 +1056,8 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
       if (clo >= chi) break;
       WalkArgs w = walk_args(0, clo, chi, queues + c);
       prof_begin(b, EV_WALK);
-      HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(chi - clo, b->walk_slots), b->stream));
+      b->n_walk_dispatch++;
+    HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(chi - clo, b->walk_slots), b->stream));
       prof_end(b);
       HIP_TRY(next_sync_event(b, &ev));
       HIP_TRY(hipEventRecord(ev, b->stream));
@@ -1080,6 +1083,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     d.eps_out = b->d_eps0.p;
     d.key_out = b->d_lkey_a.p;
     prof_begin(b, EV_WALK);
+    b->n_walk_dispatch++;
     HIP_TRY(hnyk_walk(b->g, d, b->shape, grid, b->stream));
     HIP_TRY(hnyk_iota_u64(b->d_perm_a.p, lo, cnt, b->stream));
     size_t tmp = b->sort_tmp_bytes;
@@ -1089,6 +1093,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.first = 0;
     w.eps_in = b->d_eps0.p;
     w.perm = b->d_perm_b.p;
+    b->n_walk_dispatch++;
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
     prof_end(b);
     PruneArgs p = prune_args(0, lo, hi);
@@ -1102,6 +1107,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
     WalkArgs w = walk_args(l, lo, hi, queues + (l & 7));
     prof_begin(b, EV_WALK);
+    b->n_walk_dispatch++;
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
     prof_end(b);
     prof_begin(b, EV_PRUNE);
@@ -1299,7 +1305,8 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
     g->t_prune_kernels_s = acc[EV_PRUNE];
     g->t_sort_kernels_s = acc[EV_SORT];
     g->t_apply_kernels_s = acc[EV_APPLY];
-    g->n_walk_launches = cnt[EV_WALK];
+    (void)cnt;
+    g->n_walk_launches = b->n_walk_dispatch; // k_walk dispatches (rocprofv3 counts the same)
   }
   *out = g;
   return HNY_OK;
@@ -1504,7 +1511,8 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
       d.descend_only = 1;
       d.eps_out = b->d_eps0.p;
       d.key_out = b->d_lkey_a.p;
-      HIP_TRY(hnyk_walk(b->g, d, b->shape, grid, b->stream));
+      b->n_walk_dispatch++;
+    HIP_TRY(hnyk_walk(b->g, d, b->shape, grid, b->stream));
       HIP_TRY(hnyk_iota_u64(b->d_perm_a.p, 0, cnt, b->stream));
       size_t tmp = b->sort_tmp_bytes;
       HIP_TRY(hnyk_sort_pairs48(b->d_sort_tmp.p, tmp, b->d_lkey_a.p, b->d_lkey_b.p, b->d_perm_a.p,
@@ -1514,6 +1522,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
       w.perm = b->d_perm_b.p;
       w.queue = queues + 1;
     }
+    b->n_walk_dispatch++;
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
     HIP_TRY(hnyk_take_topk(dcand.p, dcn.p, rcap, k, cnt, dtop.p, b->stream));
     HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
