@@ -515,3 +515,20 @@ def test_lds_visited_table_and_spill_equal_oracle(orc, hny, slots, monkeypatch):
             c = int(want[2][r])
             assert np.array_equal(got_[0][r, :c], want[0][r, :c])
             assert np.array_equal(got_[1][r, :c].view(np.uint32), want[1][r, :c].view(np.uint32))
+
+
+@pytest.mark.parametrize("env", [{"HNY_OVERLAP": "1"}, {"HNY_PRUNE_NW": "8"}, {"HNY_NO_LOCALITY": "1"},
+                                 {"HNY_STAGE_BYTES": "0"}, {"HNY_STAGE_BYTES": "8192", "HNY_PRUNE_NW": "8"}])
+def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
+    """Every measured-and-rejected variant that is still selectable by environment (DESIGN.md "what
+    did not pay") must build the oracle's graph too: overlapped chunked prune, 8-wave prune chunks,
+    no locality order, no / small LDS stage."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(5)
+    n, dim, M, M0, ef = 7000, 256, 8, 16, 40
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, M, seed=9))
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=4096)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=4096)
+    _same_graph(g, o)
