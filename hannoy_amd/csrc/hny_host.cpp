@@ -1071,14 +1071,14 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     HIP_TRY(hipStreamWaitEvent(b->stream, ev, 0));
     return HNY_OK;
   }
-  if (L == 0 && b->locality && b->max_level >= 1 && cnt >= 2048) {
-    // level-0 batch in LOCALITY ORDER: (1) greedy descent for every member, recording the closest
-    // node of the last greedy layers as a coarse-to-fine key; (2) sort the members by that key;
-    // (3) layer-0 beam search and prune in that order, so that the waves running at the same time
-    // work in the same region of the graph and share candidate rows in L2 / Infinity Cache.  Results
-    // are stored per member: the build is unchanged, only its memory traffic.
+  if (b->locality && b->max_level > L && cnt >= 2048) {
+    // batch in LOCALITY ORDER: (1) greedy descent for every member, recording the closest node of
+    // the last greedy layers as a coarse-to-fine key; (2) sort the members by that key; (3) the beam
+    // searches and prunes of every layer take the members in that order, so that the waves running
+    // at the same time work in the same region of the graph and share candidate rows in L2 /
+    // Infinity Cache.  Results are stored per member: the build is unchanged, only its memory traffic.
     const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
-    WalkArgs d = walk_args(0, lo, hi, queues + 0);
+    WalkArgs d = walk_args(L, lo, hi, queues + 0);
     d.descend_only = 1;
     d.eps_out = b->d_eps0.p;
     d.key_out = b->d_lkey_a.p;
@@ -1089,18 +1089,24 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     size_t tmp = b->sort_tmp_bytes;
     HIP_TRY(hnyk_sort_pairs48(b->d_sort_tmp.p, tmp, b->d_lkey_a.p, b->d_lkey_b.p, b->d_perm_a.p,
                               b->d_perm_b.p, cnt, b->stream));
-    WalkArgs w = walk_args(0, lo, hi, queues + 1);
-    w.first = 0;
-    w.eps_in = b->d_eps0.p;
-    w.perm = b->d_perm_b.p;
-    b->n_walk_dispatch++;
-    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
-    prof_end(b);
-    PruneArgs p = prune_args(0, lo, hi);
-    p.perm = b->d_perm_b.p;
-    prof_begin(b, EV_PRUNE);
-    HIP_TRY(launch_prune(p, b->stream));
-    prof_end(b);
+    for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
+      WalkArgs w = walk_args(l, lo, hi, queues + ((l + 1) & 7));
+      if (l == (int32_t)L) {
+        w.first = 0;
+        w.eps_in = b->d_eps0.p;
+      } else {
+        prof_begin(b, EV_WALK);
+      }
+      w.perm = b->d_perm_b.p;
+      b->n_walk_dispatch++;
+      HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+      prof_end(b);
+      PruneArgs p = prune_args(l, lo, hi);
+      p.perm = b->d_perm_b.p;
+      prof_begin(b, EV_PRUNE);
+      HIP_TRY(launch_prune(p, b->stream));
+      prof_end(b);
+    }
     return HNY_OK;
   }
   const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);

@@ -414,3 +414,29 @@ def test_build_cancel_and_progress(H):
     w.add_items(range(500), np.random.default_rng(3).random((500, 8), dtype=np.float32))
     w.builder().progress(lambda done, total: seen.append((done, total))).build()
     assert seen and seen[-1] == (500, 500)
+
+
+def test_multithreaded_reads(H, kat):
+    """tests/test_basic.py:37-54: two threads, each with its own reader on the same database"""
+    import threading
+    k = kat["kat8"]
+    db = H.Database(None, H.Metric.HAMMING)
+    with db.writer(3, m=4, ef=10) as writer:
+        for i, v in zip(k["ids"], k["vectors"]):
+            writer.add_item(i, v)
+    got, errs = {}, []
+
+    def _read(q):
+        try:
+            reader = db.reader(0)
+            got[tuple(q)] = reader.by_vec(q, 1)
+            reader.close()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    threads = [threading.Thread(target=_read, args=(q,)) for q in ([1.0, 0.0, 0.0], [0.0, 1.0, 0.0])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    assert got[(1.0, 0.0, 0.0)] == [(0, 0.0)] and got[(0.0, 1.0, 0.0)] == [(1, 0.0)]

@@ -532,3 +532,22 @@ def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
     o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=4096)
     g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=4096)
     _same_graph(g, o)
+
+
+def test_locality_ordered_upper_level_batches_equal_oracle(orc, hny):
+    """Batches of level >= 1 with >= 2048 members are processed in locality order too (descent to
+    level+1, key sort, every layer's walk and prune through the permutation): M=4 puts 3/16 of the
+    items on level 1 exactly, so a 16k-item build has a 3072-member level-1 batch."""
+    rng = np.random.default_rng(21)
+    n, dim, M, M0, ef = 16384, 32, 4, 8, 24
+    cent = rng.uniform(-1, 1, (64, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 64, n)] + 0.2 * rng.standard_normal((n, dim))).astype(np.float32)
+    lv = np.zeros(n, np.uint8)
+    lv[::4] = 1          # 4096 items on level >= 1
+    lv[::16] = 2         # 1024 of them on level >= 2
+    lv[::256] = 3
+    ds, items = _mk(orc, hny, 1, vecs, lv)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=4.0, batch_max=4096)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=4.0, batch_max=4096)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added
