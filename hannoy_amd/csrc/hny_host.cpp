@@ -226,7 +226,7 @@ struct hny_builder {
   std::vector<uint32_t> order;        // insertion order (slots), level desc, id asc inside a level
   std::vector<uint8_t> order_level;   // level of each insertion (an item can be re-inserted)
   std::vector<int8_t> ins_level;      // highest level a slot is inserted at in this build, -1 = none
-  std::vector<uint8_t> old_mask;      // incremental: bit l = an old Links record (slot, l) exists
+  std::vector<uint16_t> old_mask;     // incremental: bit l = an old Links record (slot, l) exists
   std::vector<uint8_t> deleted;       // incremental: slot is in to_delete
   std::vector<u64> old_recs;          // incremental: surviving old records, layer << 31 | slot
   bool incremental = false;
@@ -663,8 +663,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     const hny_prev_graph *pg = inc->prev;
     for (uint64_t i = 0; i < inc->n_delete; i++) b->deleted[slot_of(inc->to_delete[i])] = 1;
     for (uint64_t r = 0; r < pg->n_records; r++) {
-      if (pg->rec_layer[r] > 7) return fail(HNY_ERR_INVALID_ARG, "old record on layer > 7");
-      b->old_mask[slot_of(pg->rec_item[r])] |= (uint8_t)(1u << pg->rec_layer[r]);
+      if (pg->rec_layer[r] > HNY_MAX_LEVEL) return fail(HNY_ERR_INVALID_ARG, "old record on layer > %d", HNY_MAX_LEVEL);
+      b->old_mask[slot_of(pg->rec_item[r])] |= (uint16_t)(1u << pg->rec_layer[r]);
     }
     std::vector<uint8_t> lv(inc->n_insert);
     if (items->levels)
@@ -693,7 +693,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     uint32_t l = max_level;
     for (size_t k = 0; k < del_eps.size(); k++) { // :243-257 replace deleted entry points
       for (;;) {
-        if (l <= 7)
+        if (l <= HNY_MAX_LEVEL)
           for (uint32_t s = 0; s < n; s++) // iter_layer_links(l): ascending item
             if (((b->old_mask[s] >> l) & 1) && !b->deleted[s] && !in_new[s]) {
               in_new[s] = 1;
@@ -728,10 +728,10 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     for (uint32_t s = 0; s < n; s++) // schedule: surviving old layer-0 records count as inserted
       if ((b->old_mask[s] & 1) && !b->deleted[s]) b->n_done0++;
     for (uint32_t s = 0; s < n; s++)
-      for (uint32_t ll = 0; ll < 8; ll++)
+      for (uint32_t ll = 0; ll <= HNY_MAX_LEVEL; ll++)
         if (((b->old_mask[s] >> ll) & 1) && !b->deleted[s]) b->old_recs.push_back(((u64)ll << 31) | s);
   }
-  if (b->max_level > 7) return fail(HNY_ERR_INVALID_ARG, "level > 7");
+  if (b->max_level > HNY_MAX_LEVEL) return fail(HNY_ERR_INVALID_ARG, "level > %d", HNY_MAX_LEVEL);
   for (auto &pr : levels) {
     b->order.push_back(pr.first);
     b->order_level.push_back(pr.second);
@@ -745,7 +745,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   b->up_layers = std::max<uint32_t>(b->max_level, 1);
   for (uint32_t s = 0; s < n; s++) {
     int top = b->ins_level[s] > 0 ? b->ins_level[s] : 0;
-    for (int ll = 7; ll > top; ll--)
+    for (int ll = HNY_MAX_LEVEL; ll > top; ll--)
       if ((b->old_mask[s] >> ll) & 1) {
         top = ll;
         break;
@@ -773,8 +773,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     b->sel_words = std::max<size_t>(b->sel_words, (size_t)(bs * (L + 1) * (cs + 1)));
     pos = e;
   }
-  if (b->max_ops >= (1ull << 30))
-    return fail(HNY_ERR_UNSUPPORTED, "batch_max too large: %zu link ops per batch >= 2^30", b->max_ops);
+  if (b->max_ops >= (1ull << HNY_SEQ_BITS))
+    return fail(HNY_ERR_UNSUPPORTED, "batch_max too large: %zu link ops per batch >= 2^%d", b->max_ops, HNY_SEQ_BITS);
   b->walk_slots = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_WALK_SLOTS", 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
@@ -844,7 +844,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_vals_a.alloc(b->max_ops));
   HIP_TRY(b->d_vals_b.alloc(b->max_ops));
   HIP_TRY(b->d_seg_start.alloc(b->max_ops));
-  HIP_TRY(b->d_nseg.alloc(16));
+  HIP_TRY(b->d_nseg.alloc(4 + 16));
   b->locality = env_int("HNY_NO_LOCALITY", 0) == 0;
   HIP_TRY(b->d_lkey_a.alloc(cand_rows));
   HIP_TRY(b->d_lkey_b.alloc(cand_rows));
@@ -1039,8 +1039,8 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
       return hnyk_prune(b->g, p, b->shape, (int)std::min<uint32_t>(p.hi - p.lo, b->walk_slots), st);
     return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, b->prune_nw, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
   };
-  u32 *queues = b->d_nseg.p + 4; // 8 work counters
-  HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
+  u32 *queues = b->d_nseg.p + 4; // 16 work counters: the descent + one per layer of the batch
+  HIP_TRY(hipMemsetAsync(queues, 0, 16 * 4, b->stream));
 
   const uint32_t cnt = hi - lo;
   if (L == 0 && b->overlap && cnt >= 8192) {
@@ -1090,7 +1090,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     HIP_TRY(hnyk_sort_pairs48(b->d_sort_tmp.p, tmp, b->d_lkey_a.p, b->d_lkey_b.p, b->d_perm_a.p,
                               b->d_perm_b.p, cnt, b->stream));
     for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
-      WalkArgs w = walk_args(l, lo, hi, queues + ((l + 1) & 7));
+      WalkArgs w = walk_args(l, lo, hi, queues + (l + 1));
       if (l == (int32_t)L) {
         w.first = 0;
         w.eps_in = b->d_eps0.p;
@@ -1111,7 +1111,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   }
   const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
   for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
-    WalkArgs w = walk_args(l, lo, hi, queues + (l & 7));
+    WalkArgs w = walk_args(l, lo, hi, queues + l);
     prof_begin(b, EV_WALK);
     b->n_walk_dispatch++;
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));

@@ -14,6 +14,10 @@ typedef unsigned int u32;
 #define HNY_POOL_CAP 128          // tie pool (DESIGN.md "candidate heap")
 #define HNY_MAX_EF 512
 #define HNY_OP_INVALID 0xFFFFFFFFFFFFFFFFull
+// link-op sort key: layer:4 | target:31 | sequence:29 (levels 0..14: M = 4 draws up to level 14 before
+// its probability drops under the 1e-9 cut of get_default_probas, hnsw.rs:94-110)
+#define HNY_SEQ_BITS 29
+#define HNY_MAX_LEVEL 14
 
 // metric classes of the inner loop
 enum { MC_DOT = 0, MC_L2 = 1, MC_L1 = 2, MC_BIN = 3 };

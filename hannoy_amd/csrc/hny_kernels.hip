@@ -1677,8 +1677,8 @@ __global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g, PruneArgs a, i
 
 // ---------------------------------------------------------------------------------------------
 // link ops.  For batch member m (in batch order), layer l from its level down to 0, k-th selected
-// (d, n): LINK(q,(d,n),l) then LINK(n,(d,q),l) (hnsw.rs:316-324).  key = layer:3 | target:31 |
-// seq:30 — a full 64-bit sort groups ops by target and keeps the reference's sequential order
+// (d, n): LINK(q,(d,n),l) then LINK(n,(d,q),l) (hnsw.rs:316-324).  key = layer:4 | target:31 |
+// seq:29 — a full 64-bit sort groups ops by target and keeps the reference's sequential order
 // inside each target; ops on different targets commute.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_emit(GraphDev g, EmitArgs a) {
@@ -1696,9 +1696,9 @@ __global__ void k_emit(GraphDev g, EmitArgs a) {
     u64 nb = e & 0xFFFFFFFFull, db = e >> 32;
     u64 q = a.q_slots[m];
     u64 layer = (u64)(a.batch_level - li);
-    a.keys[o] = (layer << 61) | (q << 30) | o;
+    a.keys[o] = (layer << (31 + HNY_SEQ_BITS)) | (q << HNY_SEQ_BITS) | o;
     a.vals[o] = (db << 32) | nb;
-    a.keys[o + 1] = (layer << 61) | (nb << 30) | (o + 1);
+    a.keys[o + 1] = (layer << (31 + HNY_SEQ_BITS)) | (nb << HNY_SEQ_BITS) | (o + 1);
     a.vals[o + 1] = (db << 32) | q;
     atomicAdd(&g.stats[ST_LINKS], 2ull); // build_stats.incr_link_count(2), hnsw.rs:323
   } else {
@@ -1712,7 +1712,7 @@ __global__ void k_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_se
   if (i >= n_ops) return;
   u64 k = keys[i];
   if (k == HNY_OP_INVALID) return;
-  if (i == 0 || (keys[i - 1] >> 30) != (k >> 30)) seg_start[atomicAdd(n_seg, 1u)] = i;
+  if (i == 0 || (keys[i - 1] >> HNY_SEQ_BITS) != (k >> HNY_SEQ_BITS)) seg_start[atomicAdd(n_seg, 1u)] = i;
 }
 
 // add_link (hnsw.rs:523-560) for every op of one (layer, target), in order.
@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
   u64 evals = 0;
   for (u32 sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
     const u32 i0 = a.seg_start[sg];
-    const u64 k0 = a.keys[i0] >> 30;
+    const u64 k0 = a.keys[i0] >> HNY_SEQ_BITS;
     const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
     u32 cap, *ids, *cntp;
     float *dist;
@@ -1754,7 +1754,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
       u32 nops = 0;
       for (u32 i = i0; i < a.n_ops; i++) {
         const u64 key = a.keys[i];
-        if (key == HNY_OP_INVALID || (key >> 30) != k0) break;
+        if (key == HNY_OP_INVALID || (key >> HNY_SEQ_BITS) != k0) break;
         nops++;
         if (cnt + (int)nops > (int)cap) break;
       }
@@ -1767,7 +1767,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
     WSYNC();
     for (u32 i = i0; i < a.n_ops; i++) {
       const u64 key = a.keys[i];
-      if (key == HNY_OP_INVALID || (key >> 30) != k0) break;
+      if (key == HNY_OP_INVALID || (key >> HNY_SEQ_BITS) != k0) break;
       const u64 val = a.vals[i];
       if ((u32)(val & 0xFFFFFFFFull) == target) continue; // :530 p == q.1
       if (cnt < (int)cap) {                               // :542-545 append, no dedup
@@ -1817,7 +1817,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int S
   for (u32 di = blockIdx.x; di < n_def; di += gridDim.x) {
     const u32 sg = a.deferred[di];
     const u32 i0 = a.seg_start[sg];
-    const u64 k0 = a.keys[i0] >> 30;
+    const u64 k0 = a.keys[i0] >> HNY_SEQ_BITS;
     const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
     u32 cap, *ids, *cntp;
     float *dist;
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int S
     __syncthreads();
     for (u32 i = i0; i < a.n_ops && !frozen; i++) {
       const u64 key = a.keys[i];
-      if (key == HNY_OP_INVALID || (key >> 30) != k0) break;
+      if (key == HNY_OP_INVALID || (key >> HNY_SEQ_BITS) != k0) break;
       const u64 val = a.vals[i];
       if ((u32)(val & 0xFFFFFFFFull) == target) continue; // hnsw.rs:530
       if (cnt < (int)cap) {                               // :542-545

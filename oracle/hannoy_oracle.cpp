@@ -1024,7 +1024,7 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
   for (uint64_t i = 0; i < n_delete; i++) del[slot(to_delete[i])] = 1;
 
   /* the previous graph as LMDB holds it */
-  const uint32_t MAXL = 8;
+  const uint32_t MAXL = 15; /* M = 4 draws levels up to 14 (hnsw.rs:94-110) */
   B.disk.assign(MAXL, std::vector<std::vector<uint32_t>>(n));
   B.has_disk.assign(MAXL, std::vector<uint8_t>(n, 0));
   for (uint64_t r = 0; r < prev->n_records; r++) {

@@ -551,3 +551,41 @@ def test_locality_ordered_upper_level_batches_equal_oracle(orc, hny):
     g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=4.0, batch_max=4096)
     _same_graph(g, o)
     assert g.n_links_added == o.n_links_added
+
+
+def test_levels_up_to_14(orc, hny):
+    """get_default_probas (hnsw.rs:94-110) cuts at 1e-9: M = 4 reaches level 14.  A fresh build with a
+    few items on levels 8..14, then an incremental round on top (the top items deleted, a new level-11
+    item inserted), GPU == oracle; the search descends through all the layers."""
+    rng = np.random.default_rng(14)
+    n, dim, M, M0, ef = 2500, 24, 4, 8, 24
+    vecs = rng.uniform(-1, 1, (n + 50, dim)).astype(np.float32)
+    lv = draw_levels(n, M, seed=2)
+    lv[[7, 300, 900]] = [14, 14, 12]
+    lv[[11, 1200, 2000, 2400]] = [9, 8, 10, 8]
+    kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=0.5, batch_max=256)
+    kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=0.5, batch_max=256)
+    ds = orc.Dataset.from_f32(1, vecs[:n], lv)
+    items = hny.ItemSet(1, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    og = orc.build(ds, **kw_o)
+    with hny.Builder(items, **kw_g) as b:
+        b.run()
+        gg = b.finish()
+        qc = orc.encode_vectors(1, vecs[n:])
+        qh = orc.make_headers(1, dim, qc)
+        got = b.search_knn(qc, qh, k=5, ef_search=30)
+    assert gg.max_level == 14 and gg.entry_points.tolist() == [7, 300]
+    _same_graph(gg, og)
+    want = orc.search(ds, gg, qc, qh, k=5, ef_search=30, order=orc.ORDER_WAVE, threads=4)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    # incremental: both entry points and a level-10 item go, 50 items come, one of them on level 11
+    to_delete = [7, 300, 2000]
+    keep = np.array([i for i in range(n + 50) if i not in to_delete], np.uint32)
+    to_insert = list(range(n, n + 50))
+    ins_lv = draw_levels(50, M, seed=3)
+    ins_lv[10] = 11
+    ds2 = orc.Dataset.from_f32(1, vecs[keep], np.zeros(len(keep), np.uint8), keep)
+    items2 = hny.ItemSet(1, dim, ds2.ids, ds2.codes, ds2.headers, ins_lv)
+    og2 = orc.build_incremental(ds2, og, to_insert, ins_lv, to_delete, **kw_o)
+    gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
+    _same_graph(gg2, og2)
