@@ -296,12 +296,15 @@ struct hny_builder {
 enum { EV_WALK = 0, EV_PRUNE = 1, EV_SORT = 2, EV_APPLY = 3, EV_KINDS = 4 };
 // LDS visited table of a walk wave: what is left of a 10 KB share (16 waves per CU in 160 KB) after
 // the beam, in whole 64-entry rows
+static uint32_t eps_cap_of(const hny_builder *b) {
+  return (uint32_t)std::max<size_t>(64, (b->entry_points.size() + 63) / 64 * 64);
+}
 static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
   if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
   // measured: +5 % on 3 KB rows (C2/C3), -3 % on 512-B rows (the table clear per greedy layer and
   // the longer probes outweigh the saved L2 atomics when a row costs little): rows >= 1 KB only
   if ((size_t)b->g.n16 * 16 < 1024) return 0;
-  const size_t fixed = hnyk_walk_lds_bytes(rcap);
+  const size_t fixed = hnyk_walk_lds_bytes(rcap, eps_cap_of(b));
   if (fixed + 512 * 4 > 10240) return 512;
   return (uint32_t)((10240 - fixed) / 4 / 64 * 64);
 }
@@ -829,7 +832,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(hipHostMalloc((void **)&b->h_cnt0, nn * 4));
   HIP_TRY(hipHostMalloc((void **)&b->h_up, std::max<size_t>(nup * o.M, 1) * 4));
   HIP_TRY(hipHostMalloc((void **)&b->h_cntu, std::max<size_t>(nup, 1) * 4));
-  HIP_TRY(b->d_eps.alloc(HNY_MAX_EPS));
+  HIP_TRY(b->d_eps.alloc(std::max<size_t>(64, b->entry_points.size())));
   HIP_TRY(b->d_stats.alloc(ST_COUNT));
   const uint32_t slots = std::min<uint32_t>(b->walk_slots, std::max<uint32_t>(b->max_batch, 256));
   b->walk_slots = slots;
@@ -1015,6 +1018,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
     w.vis_slots = vis_slots_for(b, w.rcap);
+    w.eps_cap = eps_cap_of(b);
     w.queue = queue;
     return w;
   };
@@ -1508,6 +1512,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
     w.vis_slots = vis_slots_for(b, w.rcap);
+    w.eps_cap = eps_cap_of(b);
     w.queue = queues;
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
@@ -1701,6 +1706,7 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     a.vlog = b->d_vlog.p;
     a.log_cap = b->log_cap;
     a.vis_slots = vis_slots_for(b, a.rcap);
+    a.eps_cap = eps_cap_of(b);
     a.queue = queues;
     a.status = dstatus.p;
     a.cand_slots = dcslots.p;

@@ -10,7 +10,7 @@ typedef unsigned int u32;
 
 #define HNY_SENT 0xFFFFFFFFu      // empty neighbour slot
 #define HNY_MAX_CAP 64            // max(M, M0): one lane per neighbour
-#define HNY_MAX_EPS 64            // max entry points / eps per walk
+#define HNY_MAX_EPS 2048          // max entry points (every item of a small all-level-0 index is one)
 #define HNY_POOL_CAP 128          // tie pool (DESIGN.md "candidate heap")
 #define HNY_MAX_EF 512
 #define HNY_OP_INVALID 0xFFFFFFFFFFFFFFFFull
@@ -107,6 +107,7 @@ struct WalkArgs {
   u32 knn_k;        // reader mode: wanted hits (exhaustive fallback below that, reader.rs:771-795)
   u32 knn_ef;       // reader mode: opt.ef of the query builder
   u32 vis_slots;    // LDS visited table entries per wave (0: HBM bitset only)
+  u32 eps_cap;      // LDS entries of the eps array: >= max(64, n_entry_points)
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -135,6 +136,7 @@ struct NnsArgs {
   u32 heap_cap;
   u32 *queue;
   u32 vis_slots;               // LDS visited table entries per wave
+  u32 eps_cap;                 // LDS entries of the eps array
   u32 *status;                 // [n_queries] 1 = the heap overflowed: run again with a larger one
   // brute_force_search (reader.rs:667-711): the existing candidates, ascending
   const u32 *cand_slots;
@@ -204,6 +206,6 @@ hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);
 hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
                           LaunchShape s, hipStream_t st);
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st);
-size_t hnyk_walk_lds_bytes(u32 rcap);
+size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
 hipError_t hnyk_norms_x86(const float *v, u32 dim, u64 n, float *out, hipStream_t st);
 hipError_t hnyk_quantize(const float *v, u32 dim, u64 n, int binary_codec, u64 *out, hipStream_t st);

@@ -660,7 +660,7 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 }
 
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
-template <int LPR, int NCH>
+template <int LPR, int NCH, bool BIG_EPS>
 __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
@@ -672,17 +672,23 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
   s.tie_bits = 0;
   s.dropped = false;
   // :474-481 every entry point goes to candidates and res (no capacity check) and is visited
-  {
-    u32 id = ln < n_eps ? eps[ln] : 0u;
-    bool isnew = visited_insert(vis, id, ln < n_eps);
+  // (64 at a time: a small index whose items all drew level 0 has every item as an entry point)
+  // (BIG_EPS: more than 64 of them, 64 at a time — a small index whose items all drew level 0 has
+  // every item as an entry point; a separate instantiation so that the common kernel keeps its
+  // register allocation)
+  for (int e0 = 0; e0 < (BIG_EPS ? n_eps : 1); e0 += 64) {
+    const int ne = BIG_EPS ? (n_eps - e0 < 64 ? n_eps - e0 : 64) : n_eps;
+    u32 id = ln < ne ? eps[e0 + ln] : 0u;
+    bool isnew = visited_insert(vis, id, ln < ne);
     u64 nmask = __ballot(isnew);
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
-    if (ln < n_eps) nb_ids[ln] = id;
+    if (BIG_EPS) WSYNC();
+    if (ln < ne) nb_ids[ln] = id;
     WSYNC();
-    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_eps, nb_d, qrow);
-    evals += (u64)n_eps;
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
+    evals += (u64)ne;
     WSYNC();
-    for (int r = 0; r < n_eps; r++) {
+    for (int r = 0; r < ne; r++) {
       u64 key = ((u64)uni(fbits(nb_d[r])) << 32) | ((u64)uni(nb_ids[r]) << 1);
       beam_insert(s, key, 0x7FFFFFFF);
     }
@@ -834,7 +840,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 4
 #endif
-template <int LPR, int NCH>
+template <int LPR, int NCH, bool BIG_EPS>
 __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g, WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
   s.dropped = false;
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
-               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + HNY_MAX_EPS, a.vis_slots);
+               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u), a.vis_slots);
   u64 evals = 0;
   u32 err_iter = 0, log_over_cnt = 0;
 
@@ -885,7 +891,11 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
     u32 start_layer;
     if (a.first) { // :298 eps = all entry points
       n_eps = (int)a.n_entry_points;
-      if (ln < n_eps) eps[ln] = a.entry_points[ln];
+      if (BIG_EPS) {
+        for (int i = ln; i < n_eps; i += 64) eps[i] = a.entry_points[i];
+      } else if (ln < n_eps) {
+        eps[ln] = a.entry_points[ln];
+      }
       start_layer = g.max_level;
     } else if (a.eps_in) { // resume after a descend_only launch
       n_eps = 1;
@@ -903,7 +913,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+      walk_one_layer<LPR, NCH, BIG_EPS>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                nb_d, evals, err_iter, qrow);
       if (last) break;
       // :305-306 eps = [closest]
@@ -963,7 +973,7 @@ __global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE))
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
+        walk_one_layer<LPR, NCH, BIG_EPS>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
@@ -1113,17 +1123,20 @@ __device__ int visit_filtered(const GraphDev &g, const float4 (&q)[NCH], float q
   res_len = 0;
   Q.size = 0;
   Q.top = ~0ull;
-  { // :316-325 every entry point is queued and visited; res takes it only if the filter does
-    u32 id = ln < n_eps ? eps[ln] : 0u;
-    bool isnew = visited_insert(vis, id, ln < n_eps);
+  // :316-325 every entry point is queued and visited; res takes it only if the filter does
+  for (int e0 = 0; e0 < n_eps; e0 += 64) {
+    const int ne = n_eps - e0 < 64 ? n_eps - e0 : 64;
+    u32 id = ln < ne ? eps[e0 + ln] : 0u;
+    bool isnew = visited_insert(vis, id, ln < ne);
     u64 nmask = __ballot(isnew);
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
-    if (ln < n_eps) nb_ids[ln] = id;
     WSYNC();
-    dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_eps, nb_d, qrow);
-    evals += (u64)n_eps;
+    if (ln < ne) nb_ids[ln] = id;
     WSYNC();
-    for (int r = 0; r < n_eps; r++) {
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
+    evals += (u64)ne;
+    WSYNC();
+    for (int r = 0; r < ne; r++) {
       const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
       if (!qheap_push(Q, ((u64)db << 32) | (u64)(~idr))) return 1;
       if (in_filter(filter, excl, idr)) sorted_insert(res, res_len, ((u64)db << 32) | idr, 0x7FFFFFFF, rcap, res_err);
@@ -1199,7 +1212,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
   s.dropped = false;
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
-               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + HNY_MAX_EPS, a.vis_slots);
+               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + a.eps_cap, a.vis_slots);
   QHeap Q;
   Q.h = a.heap + (size_t)blockIdx.x * a.heap_cap;
   Q.cap = a.heap_cap;
@@ -1234,10 +1247,10 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
       WSYNC();
     } else { // :728-743 greedy descent, no filter, `path` shared and cleared before level 0
       n_eps = (int)a.n_entry_points;
-      if (ln < n_eps) eps[ln] = a.entry_points[ln];
+      for (int i = ln; i < n_eps; i += 64) eps[i] = a.entry_points[i];
       WSYNC();
       for (u32 layer = g.max_level; layer >= 1u; layer--) {
-        walk_one_layer<LPR, NCH>(g, q, qn, layer, 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
+        walk_one_layer<LPR, NCH, true>(g, q, qn, layer, 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
         const u32 closest = uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
         WSYNC();
         if (ln == 0) eps[0] = closest;
@@ -2171,15 +2184,18 @@ hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
 template <int L, int C>
 struct WalkLauncher {
   static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
-    size_t lds = hnyk_walk_lds_bytes(a.rcap) + (size_t)a.vis_slots * 4;
-    hipLaunchKernelGGL((k_walk<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    size_t lds = hnyk_walk_lds_bytes(a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
+    if (a.eps_cap > 64)
+      hipLaunchKernelGGL((k_walk<L, C, true>), dim3(grid), dim3(64), lds, st, g, a);
+    else
+      hipLaunchKernelGGL((k_walk<L, C, false>), dim3(grid), dim3(64), lds, st, g, a);
     return hipGetLastError();
   }
 };
 template <int L, int C>
 struct NnsFilteredLauncher {
   static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
-    size_t lds = hnyk_walk_lds_bytes(a.rcap) + (size_t)a.vis_slots * 4;
+    size_t lds = hnyk_walk_lds_bytes(a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
     hipLaunchKernelGGL((k_nns_filtered<L, C>), dim3(grid), dim3(64), lds, st, g, a);
     return hipGetLastError();
   }
@@ -2256,8 +2272,8 @@ struct PairLauncher {
 
 } // namespace
 
-size_t hnyk_walk_lds_bytes(u32 rcap) {
-  return (size_t)rcap * 8 + HNY_POOL_CAP * 8 + 64 * 4 * 2 + HNY_MAX_EPS * 4;
+size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap) {
+  return (size_t)rcap * 8 + HNY_POOL_CAP * 8 + 64 * 4 * 2 + (size_t)eps_cap * 4;
 }
 
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {

@@ -589,3 +589,39 @@ def test_levels_up_to_14(orc, hny):
     og2 = orc.build_incremental(ds2, og, to_insert, ins_lv, to_delete, **kw_o)
     gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
     _same_graph(gg2, og2)
+
+
+@pytest.mark.parametrize("metric,n,dim", [(1, 300, 16), (0, 700, 768), (3, 130, 256)])
+def test_every_item_an_entry_point(orc, hny, metric, n, dim):
+    """A small index whose items all drew level 0 (M=32, n=100: 4 % of the seeds) has every item as an
+    entry point (hnsw.rs:278-285): all of them seed every walk.  Fresh build, search, and an
+    incremental round that keeps max_level 0."""
+    rng = np.random.default_rng(n)
+    vecs = rng.uniform(-1, 1, (n + 40, dim)).astype(np.float32)
+    kw_o = dict(M=8, M0=16, ef=32, order=orc.ORDER_WAVE, batch_frac=0.5, batch_max=64)
+    kw_g = dict(M=8, M0=16, ef_construction=32, batch_frac=0.5, batch_max=64)
+    ds = orc.Dataset.from_f32(metric, vecs[:n], np.zeros(n, np.uint8))
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    og = orc.build(ds, **kw_o)
+    qc = orc.encode_vectors(metric, vecs[n:])
+    qh = orc.make_headers(metric, dim, qc)
+    with hny.Builder(items, **kw_g) as b:
+        b.run()
+        gg = b.finish()
+        got = b.search_knn(qc, qh, k=5, ef_search=20)
+        goti = b.nns(k=5, ef_search=20, query_items=ds.ids[:50])
+    assert gg.max_level == 0 and len(gg.entry_points) == n
+    _same_graph(gg, og)
+    want = orc.search(ds, gg, qc, qh, k=5, ef_search=20, order=orc.ORDER_WAVE, threads=4)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    wanti = orc.search(ds, gg, None, None, k=5, ef_search=20, order=orc.ORDER_WAVE, threads=4, query_items=ds.ids[:50])
+    assert np.array_equal(goti[0], wanti[0]) and np.array_equal(goti[2], wanti[2])
+    to_delete = [3, 17]
+    keep = np.array([i for i in range(n + 40) if i not in to_delete], np.uint32)
+    to_insert = list(range(n, n + 40))
+    ins_lv = np.zeros(40, np.uint8)
+    ds2 = orc.Dataset.from_f32(metric, vecs[keep], np.zeros(len(keep), np.uint8), keep)
+    items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, ins_lv)
+    og2 = orc.build_incremental(ds2, og, to_insert, ins_lv, to_delete, **kw_o)
+    gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
+    _same_graph(gg2, og2)
