@@ -27,7 +27,10 @@ EXPORTED = [
     "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels", "hny_build_incremental",
     "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
     "hny_builder_nns", "hny_draw_levels_from_seed", "hny_builder_load",
+    "hny_lmdb_writer_open", "hny_lmdb_writer_put", "hny_lmdb_writer_finish", "hny_lmdb_writer_abort",
+    "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
 ]
+ERR_IO = -9
 NNS_NONE = 0xFFFFFFFF  # by_item: the reference returns None
 
 
@@ -51,6 +54,12 @@ CANCEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 KV_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8),
                       C.c_size_t)
+
+
+class LmdbStat(C.Structure):
+    _fields_ = [("page_size", C.c_uint32), ("depth", C.c_uint32), ("branch_pages", C.c_uint64),
+                ("leaf_pages", C.c_uint64), ("overflow_pages", C.c_uint64), ("entries", C.c_uint64),
+                ("last_pgno", C.c_uint64), ("txnid", C.c_uint64), ("map_size", C.c_uint64)]
 
 
 class BuildOpts(C.Structure):
@@ -171,6 +180,22 @@ def load_library():
     L.hny_encode_kv.restype = C.c_int
     L.hny_encode_kv.argtypes = [C.POINTER(GraphStruct), C.POINTER(BuildOpts), C.POINTER(Items),
                                 C.c_uint16, C.c_int, KV_SINK, vp]
+    L.hny_lmdb_writer_open.restype = C.c_int
+    L.hny_lmdb_writer_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp)]
+    L.hny_lmdb_writer_put.restype = C.c_int
+    L.hny_lmdb_writer_put.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.hny_lmdb_writer_finish.restype = C.c_int
+    L.hny_lmdb_writer_finish.argtypes = [vp]
+    L.hny_lmdb_writer_abort.argtypes = [vp]
+    L.hny_lmdb_open.restype = C.c_int
+    L.hny_lmdb_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.hny_lmdb_stat_get.restype = C.c_int
+    L.hny_lmdb_stat_get.argtypes = [vp, C.POINTER(LmdbStat)]
+    L.hny_lmdb_get.restype = C.c_int
+    L.hny_lmdb_get.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.hny_lmdb_scan.restype = C.c_int
+    L.hny_lmdb_scan.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, KV_SINK, vp]
+    L.hny_lmdb_close.argtypes = [vp]
     L.hny_last_error.restype = C.c_char_p
     L.hny_version.restype = C.c_char_p
     _lib = L
@@ -341,6 +366,89 @@ class Graph:
         _check(load_library().hny_encode_kv(self._gp, C.byref(self._opts), C.byref(it), index,
                                             int(with_items), cb, None))
         return out
+
+
+class LmdbWriter:
+    """hny_lmdb_writer_*: bulk loader of an LMDB `data.mdb` (keys strictly ascending)."""
+
+    def __init__(self, path, name=None, page_size=0, map_size=0):
+        self._w = C.c_void_p()
+        _check(load_library().hny_lmdb_writer_open(os.fsencode(path), page_size, map_size,
+                                                   None if name is None else name.encode(), C.byref(self._w)))
+
+    @property
+    def handle(self):
+        return self._w
+
+    def put(self, k, v):
+        _check(load_library().hny_lmdb_writer_put(self._w, k, len(k), v, len(v)))
+
+    def finish(self):
+        w, self._w = self._w, None
+        _check(load_library().hny_lmdb_writer_finish(w))
+
+    def abort(self):
+        if self._w is not None:
+            load_library().hny_lmdb_writer_abort(self._w)
+            self._w = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.finish()
+        else:
+            self.abort()
+        return False
+
+
+class LmdbEnv:
+    """hny_lmdb_open / get / scan: read side of a `data.mdb` (RoTxn + Database::get / iter)."""
+
+    def __init__(self, path, name=None):
+        self._e = C.c_void_p()
+        _check(load_library().hny_lmdb_open(os.fsencode(path), None if name is None else name.encode(),
+                                            C.byref(self._e)))
+
+    def stat(self):
+        st = LmdbStat()
+        _check(load_library().hny_lmdb_stat_get(self._e, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in LmdbStat._fields_}
+
+    def get(self, k):
+        val, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = load_library().hny_lmdb_get(self._e, k, len(k), C.byref(val), C.byref(n))
+        if rc < 0:
+            _check(rc)
+        return C.string_at(val, n.value) if rc == 1 else None
+
+    def items(self, lo=None, hi=None):
+        """(key, value) pairs with lo <= key <= hi in key order; a full scan also verifies the
+        page counts of the MDB_db record"""
+        out = []
+
+        def sink(_ctx, k, kl, v, vl):
+            out.append((C.string_at(k, kl), C.string_at(v, vl)))
+            return 0
+        cb = KV_SINK(sink)
+        _check(load_library().hny_lmdb_scan(self._e, lo, len(lo) if lo else 0, hi, len(hi) if hi else 0, cb, None))
+        return out
+
+    def verify(self):
+        _check(load_library().hny_lmdb_scan(self._e, None, 0, None, 0, KV_SINK(), None))
+
+    def close(self):
+        if self._e is not None:
+            load_library().hny_lmdb_close(self._e)
+            self._e = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
 
 
 def build(items, **kw):

@@ -4,11 +4,14 @@ src/python.rs) and the build logic of `Writer::build` (/root/reference/src/write
 
 The key/value store is an in-memory ordered map holding the byte-exact hannoy records (8-byte keys,
 tagged values — key.rs:54-82, node.rs:130-174, metadata.rs:22-73, version.rs:33-60,
-update_status.rs:8-33); LMDB itself is out of scope (no LMDB in this image).  All graph work goes
+update_status.rs:8-33).  With a `path` it is persisted as an LMDB environment (`<path>/data.mdb`,
+hny_lmdb_writer_* / hny_lmdb_*: the file format of LMDB restated, there is no liblmdb in this image):
+loaded when the Database opens, rewritten when a transaction commits.  All graph work goes
 through libhannoy_amd.so (hny_build / hny_build_incremental / hny_builder_search_knn): there is no
 CPU fallback.
 """
 import enum
+import os
 import struct
 
 import numpy as np
@@ -111,12 +114,31 @@ class _StoredGraph:
 
 
 class Database:
-    """hannoy.pyi Database; `path`, `name`, `env_size` are accepted for signature parity only."""
+    """hannoy.pyi Database (python.rs:60-100): `path` = the LMDB environment directory (None = in
+    memory only), `name` = a named database inside it, `env_size` = the map size recorded in the
+    meta page."""
 
     def __init__(self, path=None, distance=Metric.COSINE, name=None, env_size=None):
         capi.load_library()
         self.distance = distance
         self.kv = {}
+        self.path, self.name, self.env_size = path, name, env_size
+        if path is not None:
+            os.makedirs(path, exist_ok=True)
+            f = os.path.join(path, "data.mdb")
+            if os.path.exists(f):
+                with capi.LmdbEnv(f, name) as env:
+                    self.kv = dict(env.items())
+
+    def commit(self):
+        """RwTxn::commit (python.rs:312): with a `path`, the records become `<path>/data.mdb`"""
+        if self.path is None:
+            return
+        tmp = os.path.join(self.path, "data.mdb.tmp")
+        with capi.LmdbWriter(tmp, self.name, 0, self.env_size or 0) as w:
+            for k in sorted(self.kv):
+                w.put(k, self.kv[k])
+        os.replace(tmp, os.path.join(self.path, "data.mdb"))
 
     def writer(self, dimensions, index=0, m=16, ef=96):
         return Writer(self, dimensions, index, m, ef)
@@ -175,6 +197,7 @@ class Writer:
     def __exit__(self, exc_type, exc, tb):
         if exc_type is None:
             self.build()
+            self.db.commit()
         return False
 
     def add_item(self, item, vector):

@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhannoy_amd.so")
-SOURCES = ["hny_host.cpp", "hny_kernels.hip"]
+SOURCES = ["hny_host.cpp", "hny_kernels.hip", "hny_lmdb.cpp"]
+HOST_ONLY = {"hny_lmdb.cpp"}  # no device code: compiled as plain C++
 HEADERS = [os.path.join(CSRC, "hny_internal.h"),
            os.path.join(os.path.dirname(HERE), "include", "hannoy_amd.h")]
 # -ffp-contract=off: FMAs only where the source says fmaf (parity with the oracle's orders);
@@ -37,7 +38,11 @@ def build(force=False, verbose=False):
     objs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        if s in HOST_ONLY:
+            cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c",
+                   os.path.join(CSRC, s), "-o", obj]
+        else:
+            cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -37,6 +37,11 @@ int fail(int code, const char *fmt, ...) {
                   hipGetErrorString(e_));                                                    \
   } while (0)
 
+} // namespace
+// error reporting for the other host translation units (hny_lmdb.cpp)
+int hny_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+namespace {
+
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

@@ -232,6 +232,46 @@ typedef int (*hny_kv_sink)(void *ctx, const uint8_t *key, size_t key_len, const 
 int hny_encode_kv(const hny_graph *g, const hny_build_opts *opts, const hny_items *items,
                   uint16_t index, int with_items, hny_kv_sink sink, void *ctx);
 
+/* ---- LMDB writeback: the KV stream above as an LMDB environment file
+ * (`<dir>/data.mdb`) that heed/LMDB can open — what `db.put` produces in the reference's write
+ * loop (hnsw.rs:195-213, writer.rs:462-480, 585-600) through heed 0.22 / LMDB 0.9 (third party,
+ * not under /root/reference: the file format of mdb.c is restated).  The writer is
+ * a bulk loader: keys must arrive in strictly ascending LMDB order (mdb_cmp_memn: bytewise, then
+ * length), which is the order hny_encode_kv emits.  The result is the state after ONE committed
+ * write transaction on a fresh environment: meta page 1 holds txnid 1, the free DB is empty, the
+ * records live in the main DB (name == NULL, `env.create_database(wtxn, None)`,
+ * src/tests/mod.rs:111) or in a named sub-DB (python.rs:75).  HNY_ERR_IO on a failed write. */
+#define HNY_ERR_IO (-9)
+typedef struct hny_lmdb_writer hny_lmdb_writer;
+int hny_lmdb_writer_open(const char *data_mdb_path, uint32_t page_size /* 0 = 4096 */,
+                         uint64_t map_size /* 0 = file size */, const char *db_name /* or NULL */,
+                         hny_lmdb_writer **out);
+/* same signature as hny_kv_sink with ctx = the writer: pass it straight to hny_encode_kv */
+int hny_lmdb_writer_put(void *writer, const uint8_t *key, size_t key_len, const uint8_t *val,
+                        size_t val_len);
+/* writes the branch pages and both meta pages, closes the file, frees the writer (also on error) */
+int hny_lmdb_writer_finish(hny_lmdb_writer *w);
+void hny_lmdb_writer_abort(hny_lmdb_writer *w);
+
+/* read side (what heed's Database::get / iter do through mdb_get / mdb_cursor_get on a RoTxn):
+ * used to load an index written by the writer above — or by the reference — back into HBM */
+typedef struct hny_lmdb_env hny_lmdb_env;
+typedef struct {
+  uint32_t page_size, depth;
+  uint64_t branch_pages, leaf_pages, overflow_pages, entries, last_pgno, txnid, map_size;
+} hny_lmdb_stat;
+int hny_lmdb_open(const char *data_mdb_path, const char *db_name /* or NULL */, hny_lmdb_env **out);
+int hny_lmdb_stat_get(const hny_lmdb_env *e, hny_lmdb_stat *out);
+/* mdb_get: *val points into the mapping (valid until hny_lmdb_close); returns 1 if found, 0 if
+ * not (MDB_NOTFOUND), < 0 on a corrupt file */
+int hny_lmdb_get(const hny_lmdb_env *e, const uint8_t *key, size_t key_len, const uint8_t **val,
+                 size_t *val_len);
+/* cursor walk MDB_SET_RANGE(lo) .. MDB_NEXT while key <= hi (NULL bounds = open), in key order;
+ * also checks the page invariants it passes (flags, bounds, key order, counts) */
+int hny_lmdb_scan(const hny_lmdb_env *e, const uint8_t *lo, size_t lo_len, const uint8_t *hi,
+                  size_t hi_len, hny_kv_sink sink, void *ctx);
+void hny_lmdb_close(hny_lmdb_env *e);
+
 const char *hny_last_error(void);
 const char *hny_version(void);
 

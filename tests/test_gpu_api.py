@@ -440,3 +440,54 @@ def test_multithreaded_reads(H, kat):
         t.join()
     assert not errs
     assert got[(1.0, 0.0, 0.0)] == [(0, 0.0)] and got[(0.0, 1.0, 0.0)] == [(1, 0.0)]
+
+
+def test_database_path_persists_as_lmdb(H, tmp_path):
+    """python.rs:60-100 + 305-314: a Database with a path is an LMDB environment; the index built
+    and committed by one handle is what a second handle opens (Reader::open, reader.rs:387-431)"""
+    from hannoy_amd import _capi as capi
+    rng = np.random.default_rng(3)
+    vecs = rng.normal(size=(3000, 48)).astype(np.float32)
+    path = str(tmp_path / "env")
+    db = H.Database(path, H.Metric.COSINE, name="vectors", env_size=1 << 30)
+    with db.writer(48, m=8, ef=64) as w:
+        w.add_items(range(3000), vecs)
+    q = rng.normal(size=(20, 48)).astype(np.float32)
+    want = db.reader(0).by_vecs(q, n=5)
+    with capi.LmdbEnv(path + "/data.mdb", "vectors") as env:
+        env.verify()
+        st = env.stat()
+        assert st["entries"] == len(db.kv) and st["map_size"] == 1 << 30
+        assert env.items() == db.dump()
+    db2 = H.Database(path, H.Metric.COSINE, name="vectors")
+    assert db2.dump() == db.dump()
+    r = db2.reader(0)
+    assert r.n_items() == 3000
+    assert all(np.array_equal(a, b) for a, b in zip(r.by_vecs(q, n=5), want))
+    # incremental update through the reopened environment, committed again
+    with db2.writer(48, m=8, ef=64) as w:
+        w.del_item(17)
+        w.add_item(5000, vecs[17])
+    db3 = H.Database(path, H.Metric.COSINE, name="vectors")
+    ids = db3.reader(0).item_ids().tolist()
+    assert 17 not in ids and 5000 in ids and db3.dump() == db2.dump()
+    db3.reader(0).assert_validity()
+
+
+def test_graph_write_lmdb_equals_record_stream(H, tmp_path):
+    """hny_encode_kv straight into hny_lmdb_writer_put: the environment holds exactly the records
+    of the stream (Item values of 3 077 B sit on overflow pages, node.rs:136-140)"""
+    from hannoy_amd import _capi as capi
+    rng = np.random.default_rng(4)
+    vecs = rng.normal(size=(4000, 768)).astype(np.float32)
+    items = H.ItemSet.from_f32(H.COSINE, vecs)
+    g = H.build(items, M=16, M0=32, ef_construction=48, seed=1)
+    p = str(tmp_path / "data.mdb")
+    g.write_lmdb(p, index=3, with_items=True)
+    recs = g.encode_kv(3, with_items=True)
+    with capi.LmdbEnv(p) as env:
+        env.verify()
+        assert env.stat()["overflow_pages"] == 4000
+        assert env.items() == recs
+        k, v = recs[-1]
+        assert env.get(k) == v and len(v) == 1 + 4 + 3072
