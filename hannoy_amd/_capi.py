@@ -367,6 +367,20 @@ class Graph:
                                             int(with_items), cb, None))
         return out
 
+    def write_lmdb(self, path, index=0, with_items=True, name=None, page_size=0, map_size=0):
+        """The records of a fresh index straight into an LMDB `data.mdb`: hny_encode_kv with
+        hny_lmdb_writer_put as its sink (no Python in the record loop)."""
+        L = load_library()
+        w = LmdbWriter(path, name, page_size, map_size)
+        it = self._items.struct()
+        sink = C.cast(L.hny_lmdb_writer_put, KV_SINK)
+        try:
+            _check(L.hny_encode_kv(self._gp, C.byref(self._opts), C.byref(it), index, int(with_items), sink, w.handle))
+        except Exception:
+            w.abort()
+            raise
+        w.finish()
+
 
 class LmdbWriter:
     """hny_lmdb_writer_*: bulk loader of an LMDB `data.mdb` (keys strictly ascending)."""

@@ -598,7 +598,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   auto b = std::unique_ptr<hny_builder, void (*)(hny_builder *)>(new hny_builder(), hny_builder_destroy);
   b->o = o;
   b->frac = o.batch_frac > 0.0 ? o.batch_frac : 1.0;
-  b->bmax = o.batch_max ? o.batch_max : 32768u;
+  b->bmax = o.batch_max ? o.batch_max : 65536u;
   b->incremental = inc != nullptr;
   uint32_t n16;
   int rc = pick_shape(o.metric, o.dim, b->shape, n16);

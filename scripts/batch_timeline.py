@@ -27,13 +27,13 @@ def main():
                 t2 = time.perf_counter()
                 rows.append((bt.count, bt.level, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
             tot = time.perf_counter() - t_all
-        small = [r for r in rows if r[0] < 32768]
+        small = [r for r in rows if r[0] < 65536]
         print(json.dumps({"frac": a.frac, "total_s_with_syncs": round(tot, 4), "n_batches": len(rows),
                           "ramp_batches": len(small),
                           "ramp_search_ms": round(sum(r[2] for r in small), 2),
                           "ramp_apply_ms": round(sum(r[3] for r in small), 2),
-                          "full_search_ms": round(sum(r[2] for r in rows if r[0] == 32768), 2),
-                          "full_apply_ms": round(sum(r[3] for r in rows if r[0] == 32768), 2)}))
+                          "full_search_ms": round(sum(r[2] for r in rows if r[0] == 65536), 2),
+                          "full_apply_ms": round(sum(r[3] for r in rows if r[0] == 65536), 2)}))
         for r in rows[:40]:
             print("count %6d level %d search %.3f ms apply %.3f ms" % r)
 

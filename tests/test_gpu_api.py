@@ -487,7 +487,9 @@ def test_graph_write_lmdb_equals_record_stream(H, tmp_path):
     recs = g.encode_kv(3, with_items=True)
     with capi.LmdbEnv(p) as env:
         env.verify()
-        assert env.stat()["overflow_pages"] == 4000
+        big = [len(v) for k, v in recs if 8 + len(k) + len(v) > 2038]  # me_nodemax on 4 KiB pages
+        assert len(big) == 4000 + 1  # every Item value + the Metadata record (8 KB item bitmap)
+        assert env.stat()["overflow_pages"] == sum((15 + n) // 4096 + 1 for n in big)
         assert env.items() == recs
         k, v = recs[-1]
         assert env.get(k) == v and len(v) == 1 + 4 + 3072
