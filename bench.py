@@ -185,7 +185,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
     # the figure comes from the committed rocprofv3 --pmc passes of this same command
     # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch
-    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_final.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_bm65536.json")
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
                   and world == 1 and not a.x86_order)
@@ -195,7 +195,7 @@ def main():
         if pk:
             total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
             roof["traffic"] = int(total / max(1, pk["launches"]))
-            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_final.json: rocprofv3 --pmc FETCH_SIZE / "
+            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_bm65536.json: rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes of this command (scripts/profile_c2.sh), 2x FETCH + "
                                       f"WRITE summed over the {pk['launches']} k_walk dispatches of one build, "
                                       "per dispatch; FETCH_SIZE counts Infinity-Cache hits too, so this is "

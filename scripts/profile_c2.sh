@@ -1,11 +1,15 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r01_c2_*_final*: run on the MI355X box from the repo root
-#   gpurun --timeout 1800 -- 'bash scripts/profile_c2.sh'
+# rocprofv3 passes behind profiles/r01_c2_*_bm65536*: run on the MI355X box from the repo root
+#   gpurun --timeout 1100 -- 'bash scripts/profile_c2.sh'
 export TMPDIR=/tmp
-out=gpurun_out/r01f
+out=gpurun_out/r01g
 rm -rf $out && mkdir -p $out
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu > $out/stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-recall --queries 0 > $out/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-recall --queries 0 > $out/write.log 2>&1
-find $out -name "*kernel_trace.csv" -size +20M -delete
+python3 scripts/pmc_summary.py $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/pmc_hbm.json > $out/pmc_summary.log 2>&1
+cp $(find $out/stats -name "*kernel_stats.csv") $out/kernel_stats.csv
+tail -1 $out/stats.log > $out/bench_under_rocprof.json
+find $out -name "*kernel_trace.csv" -delete
+find $out -name "*counter_collection.csv" -size +20M -delete
 du -sh $out
