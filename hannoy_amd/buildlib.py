@@ -32,21 +32,38 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# hny_kernels.hip is compiled once per part (see its header): 0 = general kernels + entry points,
+# 1..7 = the build kernels specialised for metric part-1
+KERNEL_PARTS = range(8)
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    objs = []
+    jobs = []
     for s in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        stem = os.path.join(CSRC, os.path.splitext(s)[0])
         if s in HOST_ONLY:
-            cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c",
-                   os.path.join(CSRC, s), "-o", obj]
+            jobs.append((stem + ".o", [hipcc(), "-O2", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c",
+                                       os.path.join(CSRC, s), "-o", stem + ".o"]))
+        elif s == "hny_kernels.hip":
+            for part in KERNEL_PARTS:
+                obj = f"{stem}_p{part}.o"
+                jobs.append((obj, [hipcc()] + FLAGS + [f"-DHNY_PART={part}", "-x", "hip", "-c",
+                                                       os.path.join(CSRC, s), "-o", obj]))
         else:
-            cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+            jobs.append((stem + ".o", [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s),
+                                                           "-o", stem + ".o"]))
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[1]), flush=True)
+        subprocess.check_call(job[1])
+        return job[0]
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(len(jobs), int(os.environ.get("HNY_BUILD_JOBS", os.cpu_count() or 1))))
+    with ThreadPoolExecutor(workers) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [hipcc(), "-shared", "--offload-arch=gfx950", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

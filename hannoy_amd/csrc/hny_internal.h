@@ -207,5 +207,16 @@ hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const 
                           LaunchShape s, hipStream_t st);
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st);
 size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
+// the build kernels specialised for metric N-1 (hny_kernels.hip compiled with -DHNY_PART=N)
+#define HNY_DECL_SP(N)                                                                                      \
+  hipError_t hnyk_walk_sp##N(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st); \
+  hipError_t hnyk_prune_wg_sp##N(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw,      \
+                                 int grid, hipStream_t st);                                                 \
+  hipError_t hnyk_apply_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,               \
+                              hipStream_t st);                                                              \
+  hipError_t hnyk_apply_wg_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,    \
+                                 hipStream_t st);
+HNY_DECL_SP(1) HNY_DECL_SP(2) HNY_DECL_SP(3) HNY_DECL_SP(4) HNY_DECL_SP(5) HNY_DECL_SP(6) HNY_DECL_SP(7)
+#undef HNY_DECL_SP
 hipError_t hnyk_norms_x86(const float *v, u32 dim, u64 n, float *out, hipStream_t st);
 hipError_t hnyk_quantize(const float *v, u32 dim, u64 n, int binary_codec, u64 *out, hipStream_t st);

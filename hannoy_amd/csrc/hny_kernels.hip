@@ -14,8 +14,22 @@
 // HBM-bound integer/f32 streaming work: no MFMA (see DESIGN.md for why).
 #include "hny_internal.h"
 
+#include <cstdlib>
 #include <cstring>
+// This file is compiled once per HNY_PART (hannoy_amd/buildlib.py, in parallel):
+//   part 0      every kernel with the metric / strict / incremental / reader switches at run time
+//               (the general path) + the launch entry points the host calls;
+//   part 1..7   the four build kernels specialised for metric HNY_PART-1 (`SP` below): the metric
+//               switch, strict mode, the incremental-build branches and the Reader fallback are
+//               compile-time dead there.  The general k_walk<64,3> spills 60 VGPRs at the 128 of 4
+//               waves per SIMD and issues ~270 instructions per distance evaluation; specialised
+//               it fits without scratch (C2: walk 0.353 -> 0.328 s, prune 0.109 -> 0.093 s).
+#ifndef HNY_PART
+#define HNY_PART 0
+#endif
+#if HNY_PART == 0
 #include <rocprim/device/device_radix_sort.hpp>
+#endif
 
 // block == one wave: with __launch_bounds__(64) the barrier is a wave-level fence only
 #define WSYNC() __syncthreads()
@@ -23,6 +37,19 @@
 namespace {
 
 __device__ __forceinline__ u32 fbits(float f) { return __float_as_uint(f); }
+
+// SP = 0: general kernel.  SP = metric + 1: the kernel's private copy of GraphDev carries the
+// metric as a constant and has strict mode and the incremental branches switched off, so that
+// every `g.metric` / `g.mclass` / `g.x86_order` / `g.incremental` test below folds at compile time.
+template <int SP>
+__device__ __forceinline__ void specialize(GraphDev &g) {
+  if constexpr (SP != 0) {
+    g.metric = SP - 1;
+    g.mclass = SP - 1 < 3 ? SP - 1 : (int)MC_BIN; // cosine/euclidean/manhattan = MC_DOT/MC_L2/MC_L1
+    g.x86_order = 0;
+    g.incremental = 0;
+  }
+}
 // wave-uniform values that were read from LDS or produced by a cross-lane reduction sit in VGPRs;
 // readfirstlane moves them to SGPRs (lower VGPR pressure, scalar branches)
 __device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
@@ -840,8 +867,12 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 4
 #endif
-template <int LPR, int NCH, bool BIG_EPS>
-__global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g, WalkArgs a) {
+template <int LPR, int NCH, bool BIG_EPS, int SP>
+__global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+  GraphDev g = g_in;
+  WalkArgs a = a_in;
+  specialize<SP>(g);
+  if constexpr (SP != 0) a.reader_mode = 0;
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
@@ -1667,8 +1698,10 @@ __device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL
   return L;
 }
 
-template <int LPR, int NCH, int NW>
-__global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g, PruneArgs a, int SL) {
+template <int LPR, int NCH, int NW, int SP>
+__global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g_in, PruneArgs a, int SL) {
+  GraphDev g = g_in;
+  specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *list = reinterpret_cast<u64 *>(smem);
   WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride, NW);
@@ -1729,8 +1762,10 @@ __global__ void k_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_se
 }
 
 // add_link (hnsw.rs:523-560) for every op of one (layer, target), in order.
-template <int LPR, int NCH>
-__global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
+template <int LPR, int NCH, int SP>
+__global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
+  GraphDev g = g_in;
+  specialize<SP>(g);
   __shared__ u64 lk[HNY_MAX_CAP];     // the node's list: dist bits << 32 | slot
   __shared__ u64 sorted[HNY_MAX_CAP];
   __shared__ u64 S[HNY_MAX_CAP];
@@ -1818,8 +1853,10 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g, ApplyArgs a) {
 
 // add_link for the segments k_apply deferred (their list overflows): 256 threads per segment, the
 // self-prune runs on the LDS-staged wg_prune.
-template <int LPR, int NCH>
-__global__ __launch_bounds__(256) void k_apply_wg(GraphDev g, ApplyArgs a, int SL) {
+template <int LPR, int NCH, int SP>
+__global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, int SL) {
+  GraphDev g = g_in;
+  specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *lk = reinterpret_cast<u64 *>(smem);          // [HNY_MAX_CAP] the node's list
   u64 *sorted = lk + HNY_MAX_CAP;                   // [HNY_MAX_CAP]
@@ -2181,16 +2218,60 @@ hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
   return hipErrorInvalidValue;
 }
 
-template <int L, int C>
-struct WalkLauncher {
-  static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
-    size_t lds = hnyk_walk_lds_bytes(a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
-    if (a.eps_cap > 64)
-      hipLaunchKernelGGL((k_walk<L, C, true>), dim3(grid), dim3(64), lds, st, g, a);
-    else
-      hipLaunchKernelGGL((k_walk<L, C, false>), dim3(grid), dim3(64), lds, st, g, a);
-    return hipGetLastError();
-  }
+// launchers of the four build kernels, general (SP = 0) or specialised for metric SP - 1
+template <int SP>
+struct Hot {
+  template <int L, int C>
+  struct Walk {
+    static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
+      size_t lds = hnyk_walk_lds_bytes(a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
+      if constexpr (SP == 0) {
+        if (a.eps_cap > 64) {
+          hipLaunchKernelGGL((k_walk<L, C, true, 0>), dim3(grid), dim3(64), lds, st, g, a);
+          return hipGetLastError();
+        }
+      }
+      hipLaunchKernelGGL((k_walk<L, C, false, SP>), dim3(grid), dim3(64), lds, st, g, a);
+      return hipGetLastError();
+    }
+  };
+  template <int L, int C>
+  struct PruneWg {
+    static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int nw, int grid, hipStream_t st) {
+      if constexpr (C > 8) {
+        return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
+      } else {
+        size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL, nw);
+        if constexpr (SP == 0) {
+          if (nw == 8) {
+            hipLaunchKernelGGL((k_prune_wg<L, C, 8, 0>), dim3(grid), dim3(512), lds, st, g, a, SL);
+            return hipGetLastError();
+          }
+        }
+        hipLaunchKernelGGL((k_prune_wg<L, C, 4, SP>), dim3(grid), dim3(256), lds, st, g, a, SL);
+        return hipGetLastError();
+      }
+    }
+  };
+  template <int L, int C>
+  struct ApplyWg {
+    static hipError_t run(const GraphDev &g, const ApplyArgs &a, int SL, int grid, hipStream_t st) {
+      if constexpr (C > 8) {
+        return hipErrorInvalidValue;
+      } else {
+        size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL, 4);
+        hipLaunchKernelGGL((k_apply_wg<L, C, SP>), dim3(grid), dim3(256), lds, st, g, a, SL);
+        return hipGetLastError();
+      }
+    }
+  };
+  template <int L, int C>
+  struct Apply {
+    static hipError_t run(const GraphDev &g, const ApplyArgs &a, int grid, hipStream_t st) {
+      hipLaunchKernelGGL((k_apply<L, C, SP>), dim3(grid), dim3(64), 0, st, g, a);
+      return hipGetLastError();
+    }
+  };
 };
 template <int L, int C>
 struct NnsFilteredLauncher {
@@ -2217,40 +2298,6 @@ struct PruneLauncher {
   }
 };
 template <int L, int C>
-struct PruneWgLauncher {
-  static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int nw, int grid, hipStream_t st) {
-    if constexpr (C > 8) {
-      return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
-    } else {
-      size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL, nw);
-      if (nw == 8)
-        hipLaunchKernelGGL((k_prune_wg<L, C, 8>), dim3(grid), dim3(512), lds, st, g, a, SL);
-      else
-        hipLaunchKernelGGL((k_prune_wg<L, C, 4>), dim3(grid), dim3(256), lds, st, g, a, SL);
-      return hipGetLastError();
-    }
-  }
-};
-template <int L, int C>
-struct ApplyWgLauncher {
-  static hipError_t run(const GraphDev &g, const ApplyArgs &a, int SL, int grid, hipStream_t st) {
-    if constexpr (C > 8) {
-      return hipErrorInvalidValue;
-    } else {
-      size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL, 4);
-      hipLaunchKernelGGL((k_apply_wg<L, C>), dim3(grid), dim3(256), lds, st, g, a, SL);
-      return hipGetLastError();
-    }
-  }
-};
-template <int L, int C>
-struct ApplyLauncher {
-  static hipError_t run(const GraphDev &g, const ApplyArgs &a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_apply<L, C>), dim3(grid), dim3(64), 0, st, g, a);
-    return hipGetLastError();
-  }
-};
-template <int L, int C>
 struct GapsLauncher {
   static hipError_t run(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
                         hipStream_t st) {
@@ -2272,12 +2319,53 @@ struct PairLauncher {
 
 } // namespace
 
+#define HNY_CAT2(a, b) a##b
+#define HNY_CAT(a, b) HNY_CAT2(a, b)
+#if HNY_PART != 0
+// ---- part 1..7: the build kernels specialised for one metric ----
+hipError_t HNY_CAT(hnyk_walk_sp, HNY_PART)(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid,
+                                           hipStream_t st) {
+  return dispatch_shape<Hot<HNY_PART>::Walk>(s, g, a, grid, st);
+}
+hipError_t HNY_CAT(hnyk_prune_wg_sp, HNY_PART)(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL,
+                                               int nw, int grid, hipStream_t st) {
+  return dispatch_shape<Hot<HNY_PART>::PruneWg>(s, g, a, SL, nw, grid, st);
+}
+hipError_t HNY_CAT(hnyk_apply_sp, HNY_PART)(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,
+                                            hipStream_t st) {
+  return dispatch_shape<Hot<HNY_PART>::Apply>(s, g, a, grid, st);
+}
+hipError_t HNY_CAT(hnyk_apply_wg_sp, HNY_PART)(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL,
+                                               int grid, hipStream_t st) {
+  return dispatch_shape<Hot<HNY_PART>::ApplyWg>(s, g, a, SL, grid, st);
+}
+#else
+// ---- part 0: the launch entry points ----
+// the specialised kernels serve the plain build: wave order, fresh index (HNY_NO_FAST=1 keeps every
+// launch on the general kernels)
+static bool fast_path(const GraphDev &g) {
+  const char *e = getenv("HNY_NO_FAST"); // read per launch: tests flip it inside one process
+  const bool off = e && atoi(e) != 0;
+  return !off && !g.x86_order && !g.incremental && g.metric >= 0 && g.metric < 7;
+}
+#define HNY_SP_SWITCH(fn, ...)                 \
+  switch (g.metric) {                          \
+    case 0: return fn##1(__VA_ARGS__);         \
+    case 1: return fn##2(__VA_ARGS__);         \
+    case 2: return fn##3(__VA_ARGS__);         \
+    case 3: return fn##4(__VA_ARGS__);         \
+    case 4: return fn##5(__VA_ARGS__);         \
+    case 5: return fn##6(__VA_ARGS__);         \
+    default: return fn##7(__VA_ARGS__);        \
+  }
+
 size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap) {
   return (size_t)rcap * 8 + HNY_POOL_CAP * 8 + 64 * 4 * 2 + (size_t)eps_cap * 4;
 }
 
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
-  return dispatch_shape<WalkLauncher>(s, g, a, grid, st);
+  if (fast_path(g) && !a.reader_mode && a.eps_cap <= 64) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
+  return dispatch_shape<Hot<0>::Walk>(s, g, a, grid, st);
 }
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<NnsFilteredLauncher>(s, g, a, grid, st);
@@ -2289,15 +2377,18 @@ hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int 
   return dispatch_shape<PruneLauncher>(s, g, a, grid, st);
 }
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st) {
-  return dispatch_shape<ApplyLauncher>(s, g, a, grid, st);
+  if (fast_path(g)) { HNY_SP_SWITCH(hnyk_apply_sp, g, a, s, grid, st) }
+  return dispatch_shape<Hot<0>::Apply>(s, g, a, grid, st);
 }
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st) {
-  return dispatch_shape<PruneWgLauncher>(s, g, a, SL, nw, grid, st);
+  if (fast_path(g) && nw == 4) { HNY_SP_SWITCH(hnyk_prune_wg_sp, g, a, s, SL, nw, grid, st) }
+  return dispatch_shape<Hot<0>::PruneWg>(s, g, a, SL, nw, grid, st);
 }
 hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
                          hipStream_t st) {
-  return dispatch_shape<ApplyWgLauncher>(s, g, a, SL, grid, st);
+  if (fast_path(g)) { HNY_SP_SWITCH(hnyk_apply_wg_sp, g, a, s, SL, grid, st) }
+  return dispatch_shape<Hot<0>::ApplyWg>(s, g, a, SL, grid, st);
 }
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st) {
@@ -2381,3 +2472,4 @@ hipError_t hnyk_iota_u64(u64 *p, u32 base, u32 n, hipStream_t st) {
   hipLaunchKernelGGL(k_iota_u64, dim3((n + 255) / 256), dim3(256), 0, st, p, base, n);
   return hipGetLastError();
 }
+#endif // HNY_PART == 0

@@ -534,6 +534,25 @@ def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
     _same_graph(g, o)
 
 
+@pytest.mark.parametrize("metric", range(7))
+def test_general_and_specialised_kernels_build_the_same_graph(orc, hny, metric, monkeypatch):
+    """A plain build runs on the kernels specialised for its metric (hny_kernels.hip parts 1..7);
+    HNY_NO_FAST=1 keeps it on the general kernels (part 0: the ones strict mode, incremental builds
+    and the Reader use).  Both must give the oracle's graph, for every metric."""
+    rng = np.random.default_rng(60 + metric)
+    n, dim, M, M0, ef = 5000, 200 if metric < 3 else 1100, 8, 16, 48
+    cent = rng.uniform(-1, 1, (32, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 32, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=2))
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=2048, threads=8)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=2048)
+    _same_graph(g, o)
+    monkeypatch.setenv("HNY_NO_FAST", "1")
+    g0 = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=2048)
+    _same_graph(g0, o)
+    assert g0.n_distance_evals == g.n_distance_evals
+
+
 def test_locality_ordered_upper_level_batches_equal_oracle(orc, hny):
     """Batches of level >= 1 with >= 2048 members are processed in locality order too (descent to
     level+1, key sort, every layer's walk and prune through the permutation): M=4 puts 3/16 of the
