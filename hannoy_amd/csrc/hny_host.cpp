@@ -308,7 +308,7 @@ static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
   if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
   // measured: +5 % on 3 KB rows (C2/C3), -3 % on 512-B rows (the table clear per greedy layer and
   // the longer probes outweigh the saved L2 atomics when a row costs little): rows >= 1 KB only
-  if ((size_t)b->g.n16 * 16 < 1024) return 0;
+  if ((size_t)b->g.n16 * 16 <= 1024) return 0;
   const size_t fixed = hnyk_walk_lds_bytes(rcap, eps_cap_of(b));
   if (fixed + 512 * 4 > 10240) return 512;
   return (uint32_t)((10240 - fixed) / 4 / 64 * 64);
@@ -783,7 +783,9 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   }
   if (b->max_ops >= (1ull << HNY_SEQ_BITS))
     return fail(HNY_ERR_UNSUPPORTED, "batch_max too large: %zu link ops per batch >= 2^%d", b->max_ops, HNY_SEQ_BITS);
-  b->walk_slots = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_WALK_SLOTS", 4096)), 65536);
+  // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (5 for rows <= 1 KB, see k_walk)
+  b->walk_slots = (uint32_t)std::min<int64_t>(
+      std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 ? 5120 : 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
   b->vis_slots_env = env_int("HNY_VIS_SLOTS", -1);

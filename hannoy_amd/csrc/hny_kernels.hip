@@ -864,11 +864,14 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE
 #define HNY_WALK_WPE 4
 #endif
+// rows of at most 1 KB (NCH == 1; no LDS visited table there, so LDS allows it): the specialised
+// kernels need <= 96 VGPRs and run 5 waves per SIMD (Hamming 1024-bit: walk 0.344 -> 0.310 s; 6
+// would spill).  The general kernels already spill at 4.
 #ifndef HNY_WALK_WPE_SMALL
-#define HNY_WALK_WPE_SMALL 4
+#define HNY_WALK_WPE_SMALL 5
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP>
-__global__ __launch_bounds__(64, (NCH <= 2 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+__global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
