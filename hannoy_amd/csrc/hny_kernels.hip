@@ -870,12 +870,12 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 5
 #endif
-template <int LPR, int NCH, bool BIG_EPS, int SP>
+template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false>
 __global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
-  if constexpr (SP != 0) a.reader_mode = 0;
+  if constexpr (SP != 0) a.reader_mode = RM ? 1 : 0; // RM: the Reader's search (hny_builder_search_knn)
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
@@ -2234,6 +2234,12 @@ struct Hot {
           return hipGetLastError();
         }
       }
+      if constexpr (SP != 0) {
+        if (a.reader_mode) {
+          hipLaunchKernelGGL((k_walk<L, C, false, SP, true>), dim3(grid), dim3(64), lds, st, g, a);
+          return hipGetLastError();
+        }
+      }
       hipLaunchKernelGGL((k_walk<L, C, false, SP>), dim3(grid), dim3(64), lds, st, g, a);
       return hipGetLastError();
     }
@@ -2367,7 +2373,7 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap) {
 }
 
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
-  if (fast_path(g) && !a.reader_mode && a.eps_cap <= 64) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
+  if (fast_path(g) && a.eps_cap <= 64) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
   return dispatch_shape<Hot<0>::Walk>(s, g, a, grid, st);
 }
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
