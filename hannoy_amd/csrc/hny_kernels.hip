@@ -14,6 +14,7 @@
 // HBM-bound integer/f32 streaming work: no MFMA (see DESIGN.md for why).
 #include "hny_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 // This file is compiled once per HNY_PART (hannoy_amd/buildlib.py, in parallel):
@@ -1733,35 +1734,60 @@ __global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g_in, PruneArgs a
 __global__ void k_emit(GraphDev g, EmitArgs a) {
   const u32 n_layers = a.batch_level + 1;
   const u64 total = (u64)a.count * n_layers * a.cap_sel;
-  u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  u32 k = (u32)(idx % a.cap_sel);
-  u32 li = (u32)((idx / a.cap_sel) % n_layers);
-  u32 m = (u32)(idx / ((u64)a.cap_sel * n_layers));
-  const u64 *s = a.sel + (size_t)m * a.sel_stride + (size_t)li * (a.cap_sel + 1);
-  u64 o = idx * 2;
-  if (k < (u32)s[0]) {
-    u64 e = s[1 + k];
-    u64 nb = e & 0xFFFFFFFFull, db = e >> 32;
-    u64 q = a.q_slots[m];
-    u64 layer = (u64)(a.batch_level - li);
-    a.keys[o] = (layer << (31 + HNY_SEQ_BITS)) | (q << HNY_SEQ_BITS) | o;
-    a.vals[o] = (db << 32) | nb;
-    a.keys[o + 1] = (layer << (31 + HNY_SEQ_BITS)) | (nb << HNY_SEQ_BITS) | (o + 1);
-    a.vals[o + 1] = (db << 32) | q;
-    atomicAdd(&g.stats[ST_LINKS], 2ull); // build_stats.incr_link_count(2), hnsw.rs:323
-  } else {
-    a.keys[o] = HNY_OP_INVALID;
-    a.keys[o + 1] = HNY_OP_INVALID;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  u64 links = 0;
+  // grid-stride: one element per thread meant 17 k workgroups per batch, and launching them was
+  // the kernel's whole duration; both ops of a pair go out as one 16-byte store
+  for (u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    u32 k = (u32)(idx % a.cap_sel);
+    u32 li = (u32)((idx / a.cap_sel) % n_layers);
+    u32 m = (u32)(idx / ((u64)a.cap_sel * n_layers));
+    const u64 *s = a.sel + (size_t)m * a.sel_stride + (size_t)li * (a.cap_sel + 1);
+    u64 o = idx * 2;
+    ulonglong2 kk, vv;
+    if (k < (u32)s[0]) {
+      u64 e = s[1 + k];
+      u64 nb = e & 0xFFFFFFFFull, db = e >> 32;
+      u64 q = a.q_slots[m];
+      u64 layer = (u64)(a.batch_level - li);
+      kk.x = (layer << (31 + HNY_SEQ_BITS)) | (q << HNY_SEQ_BITS) | o;
+      vv.x = (db << 32) | nb;
+      kk.y = (layer << (31 + HNY_SEQ_BITS)) | (nb << HNY_SEQ_BITS) | (o + 1);
+      vv.y = (db << 32) | q;
+      *reinterpret_cast<ulonglong2 *>(a.vals + o) = vv;
+      links += 2; // build_stats.incr_link_count(2), hnsw.rs:323
+    } else {
+      kk.x = HNY_OP_INVALID;
+      kk.y = HNY_OP_INVALID;
+    }
+    *reinterpret_cast<ulonglong2 *>(a.keys + o) = kk;
   }
+  // one atomic per wave
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) links += (u64)__shfl_xor((long long)links, off, 64);
+  if ((threadIdx.x & 63) == 0 && links) atomicAdd(&g.stats[ST_LINKS], links);
 }
 
 __global__ void k_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_ops) return;
-  u64 k = keys[i];
-  if (k == HNY_OP_INVALID) return;
-  if (i == 0 || (keys[i - 1] >> HNY_SEQ_BITS) != (k >> HNY_SEQ_BITS)) seg_start[atomicAdd(n_seg, 1u)] = i;
+  const u32 stride = gridDim.x * blockDim.x;
+  const int ln = threadIdx.x & 63;
+  // grid-stride (see k_emit); one slot reservation per wave and step — the order of the segments
+  // in seg_start is free, targets are independent
+  for (u32 b0 = blockIdx.x * blockDim.x; b0 < n_ops; b0 += stride) { // b0: uniform per workgroup
+    const u32 i = b0 + threadIdx.x;
+    bool start = false;
+    if (i < n_ops) {
+      const u64 k = keys[i];
+      start = k != HNY_OP_INVALID && (i == 0 || (keys[i - 1] >> HNY_SEQ_BITS) != (k >> HNY_SEQ_BITS));
+    }
+    const u64 mk = __ballot(start);
+    if (!mk) continue;
+    const int leader = __ffsll((long long)mk) - 1;
+    u32 base = 0;
+    if (ln == leader) base = atomicAdd(n_seg, (u32)__popcll(mk));
+    base = (u32)__shfl((int)base, leader, 64);
+    if (start) seg_start[base + (u32)__popcll(mk & ((1ull << ln) - 1ull))] = i;
+  }
 }
 
 // add_link (hnsw.rs:523-560) for every op of one (layer, target), in order.
@@ -2411,13 +2437,13 @@ hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const 
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st) {
   u64 total = (u64)a.count * (a.batch_level + 1) * a.cap_sel;
   if (!total) return hipSuccess;
-  hipLaunchKernelGGL(k_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, a);
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)std::min<u64>((total + 255) / 256, 2048)), dim3(256), 0, st, g, a);
   return hipGetLastError();
 }
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st) {
   if (!n_ops) return hipSuccess;
-  hipLaunchKernelGGL(k_segments, dim3((n_ops + 255) / 256), dim3(256), 0, st, keys, n_ops, seg_start,
-                     n_seg);
+  hipLaunchKernelGGL(k_segments, dim3(std::min<u32>((n_ops + 255) / 256, 2048u)), dim3(256), 0, st, keys,
+                     n_ops, seg_start, n_seg);
   return hipGetLastError();
 }
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st) {
