@@ -325,6 +325,86 @@ def test_full_size_c2_properties(orc, hny):
     assert np.all(np.diff(dists, axis=1) >= 0)  # drain_asc
 
 
+@pytest.mark.parametrize("cfg", ["C3", "C4", "C5"])
+def test_full_size_other_baseline_configs(orc, hny, cfg):
+    """BASELINE configs C3 (1M x 768 Euclidean, M=32, efC=200), C4 (10M x 128 Cosine, M=16, efC=100)
+    and C5 (5M x 1024-bit Hamming, M=16, efC=64) at FULL size on one GPU, through size-independent
+    properties: valid records (one per layer 0..=level, lists ascending / unique / within cap, ids in
+    range), determinism (two builds, identical records; C4: one build), sampled edge distances equal
+    to the oracle's bit for bit, and the GPU searcher == the oracle's restated Reader on the GPU-built
+    graph, ids and distance bits (integer-exact for Hamming), with a sane recall."""
+    import torch
+    import zlib
+    metric, n, dim, M, M0, ef, two = {"C3": (hny.EUCLIDEAN, 1_000_000, 768, 32, 64, 200, True),
+                                      "C4": (hny.COSINE, 10_000_000, 128, 16, 32, 100, False),
+                                      "C5": (hny.HAMMING, 5_000_000, 1024, 16, 32, 64, True)}[cfg]
+    nq = 100
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    nc = 4096 if cfg == "C5" else 1024
+    centres = torch.rand((nc, dim), generator=g, device=dev) * 2 - 1
+    codes, hdrs = [], []
+    step = 1_000_000
+    for lo in range(0, n, step):  # generate and encode in slices: 10M x 128 f32 is 5 GB
+        m = min(step, n - lo)
+        which = torch.randint(0, nc, (m,), generator=g, device=dev)
+        xs = centres[which] + (0.6 if cfg == "C5" else 0.15) * torch.randn((m, dim), generator=g, device=dev)
+        c, h = hny.encode_vectors(metric, xs.cpu().numpy())
+        codes.append(c)
+        hdrs.append(h)
+        del xs
+    codes, hdrs = np.concatenate(codes), np.concatenate(hdrs)
+    which = torch.randint(0, nc, (nq,), generator=g, device=dev)
+    qx = (centres[which] + (0.6 if cfg == "C5" else 0.15) * torch.randn((nq, dim), generator=g, device=dev)).cpu().numpy()
+    qc, qh = hny.encode_vectors(metric, qx)
+    levels = hny.draw_levels(11, M, n)
+    items = hny.ItemSet(metric, dim, np.arange(n, dtype=np.uint32), codes, hdrs, levels)
+    with hny.Builder(items, M=M, M0=M0, ef_construction=ef) as b:
+        b.run()
+        g1 = b.finish()
+        ids, dists, cnt = b.search_knn(qc, qh, k=10, ef_search=100)
+        rng = np.random.default_rng(0)
+        pa, pb = [], []
+        for r in rng.integers(0, len(g1.rec_item), 300):
+            lo, hi = int(g1.offsets[r]), int(g1.offsets[r + 1])
+            if hi > lo:
+                pa.append(int(g1.rec_item[r]))
+                pb.append(int(g1.nbrs[rng.integers(lo, hi)]))
+        got = b.distances(np.array(pa, np.uint32), np.array(pb, np.uint32))
+        if two:
+            b.reset()
+            b.run()
+            g2 = b.finish()
+            crc = lambda gr: (zlib.crc32(gr.nbrs.tobytes()), zlib.crc32(gr.offsets.tobytes()),
+                              zlib.crc32(gr.rec_layer.tobytes()))
+            assert crc(g1) == crc(g2)
+    assert g1.n_tie_pool_overflow == 0
+    assert len(g1.rec_item) == int(levels.astype(np.int64).sum()) + n
+    assert g1.max_level == int(levels.max())
+    assert g1.entry_points.tolist() == np.nonzero(levels == levels.max())[0].tolist()
+    assert g1.nbrs.max() < n
+    deg = np.diff(g1.offsets.astype(np.int64))
+    assert deg[g1.rec_layer == 0].max() <= M0 and deg[g1.rec_layer > 0].max() <= M
+    assert np.array_equal(g1.rec_item[g1.rec_layer == 0], np.arange(n, dtype=np.uint32))
+    inner = np.ones(len(g1.nbrs), bool)
+    inner[g1.offsets[1:-1].astype(np.int64)] = False
+    inner[0] = False
+    assert np.all(np.diff(g1.nbrs.astype(np.int64))[inner[1:]] > 0)
+    want = np.array([orc.distance(metric, orc.ORDER_WAVE, dim, codes[i], hdrs[i], codes[j], hdrs[j])
+                     for i, j in zip(pa, pb)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the restated Reader (CPU) on the GPU-built graph returns what the GPU searcher returned
+    ds = orc.Dataset(metric, dim, items.ids, codes, hdrs, levels)
+    oi, od, oc = orc.search(ds, g1, qc, qh, k=10, ef_search=100, order=orc.ORDER_WAVE, threads=16)
+    assert np.array_equal(oc, cnt)
+    for r in range(nq):
+        c = int(cnt[r])
+        assert np.array_equal(oi[r, :c], ids[r, :c])
+        assert np.array_equal(od[r, :c].view(np.uint32), dists[r, :c].view(np.uint32))
+    assert int(cnt.min()) == 10 and np.all(np.diff(dists, axis=1) >= 0)  # drain_asc, k hits each
+
+
 def test_rccl_exchange_path_single_rank(orc, hny):
     """The multi-GPU driver's exchange on the real thing: `nccl` (= RCCL) process group with one rank,
     all_gather_into_tensor on the device selection buffer handed to the C ABI, then apply from it.
