@@ -27,6 +27,8 @@ EXPORTED = [
     "hny_encode_kv", "hny_last_error", "hny_version", "hny_draw_levels", "hny_build_incremental",
     "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
     "hny_builder_nns", "hny_draw_levels_from_seed", "hny_builder_load",
+    "hny_builder_apply_begin", "hny_builder_apply_deferred", "hny_builder_apply_merge",
+    "hny_builder_exch_stride_u64",
     "hny_lmdb_writer_open", "hny_lmdb_writer_put", "hny_lmdb_writer_finish", "hny_lmdb_writer_abort",
     "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
 ]
@@ -153,6 +155,14 @@ def load_library():
     L.hny_builder_search.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.hny_builder_apply.restype = C.c_int
     L.hny_builder_apply.argtypes = [vp, vp]
+    L.hny_builder_apply_begin.restype = C.c_int
+    L.hny_builder_apply_begin.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    L.hny_builder_apply_deferred.restype = C.c_int
+    L.hny_builder_apply_deferred.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.hny_builder_apply_merge.restype = C.c_int
+    L.hny_builder_apply_merge.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.hny_builder_exch_stride_u64.restype = C.c_uint32
+    L.hny_builder_exch_stride_u64.argtypes = [vp]
     L.hny_builder_finish.restype = C.c_int
     L.hny_builder_finish.argtypes = [vp, C.POINTER(C.POINTER(GraphStruct))]
     L.hny_builder_destroy.argtypes = [vp]
@@ -561,6 +571,22 @@ class Builder:
 
     def apply(self, sel_ptr=None):
         _check(load_library().hny_builder_apply(self._h, sel_ptr))
+
+    def apply_begin(self, sel_ptr=None):
+        """emit / sort / append links; returns the number of targets whose list must be re-pruned"""
+        n = C.c_uint32()
+        _check(load_library().hny_builder_apply_begin(self._h, sel_ptr, C.byref(n)))
+        return n.value
+
+    def apply_deferred(self, rank=0, world=1, exch_ptr=None):
+        _check(load_library().hny_builder_apply_deferred(self._h, rank, world, exch_ptr))
+
+    def apply_merge(self, exch_ptr=None, rank=0, world=1):
+        _check(load_library().hny_builder_apply_merge(self._h, exch_ptr, rank, world))
+
+    @property
+    def exch_stride_u64(self):
+        return load_library().hny_builder_exch_stride_u64(self._h)
 
     def sync(self):
         _check(load_library().hny_builder_sync(self._h))

@@ -260,7 +260,7 @@ struct hny_builder {
   DevBuf<float> d_norms, d_l0_dist, d_up_dist;
   DevBuf<int> d_upper_idx;
   DevBuf<u32> d_l0_ids, d_l0_cnt, d_up_ids, d_up_cnt, d_order, d_eps, d_bits, d_vlog, d_cand_n,
-      d_seg_start, d_nseg, d_deferred, d_fin_cnt0, d_fin_cntu, d_d0_ids, d_du_ids;
+      d_seg_start, d_nseg, d_deferred, d_deferred_b, d_fin_cnt0, d_fin_cntu, d_d0_ids, d_du_ids;
   DevBuf<unsigned char> d_has_vec, d_deleted;
   DevBuf<u64> d_old_recs, d_lkey_a, d_lkey_b, d_perm_a, d_perm_b;
   DevBuf<u32> d_eps0;
@@ -271,6 +271,8 @@ struct hny_builder {
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
   int stage_rows = 0;      // selected rows staged in LDS by the workgroup prune kernels
+  u32 cur_n_ops = 0, cur_n_def = 0; // of the batch being applied
+  bool apply_open = false;          // between hny_builder_apply_begin and _merge
   int prune_nw = 4;        // candidates per chunk (= waves per workgroup) of k_prune_wg
   int vis_slots_env = -1;  // HNY_VIS_SLOTS: LDS visited table entries per walk wave, -1 = auto
   bool wave_prune_only = false;
@@ -862,6 +864,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_perm_b.alloc(cand_rows));
   HIP_TRY(b->d_eps0.alloc(cand_rows));
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
+  HIP_TRY(b->d_deferred_b.alloc(b->max_ops));
   HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
                           b->d_vals_b.p, (u32)b->max_ops, st));
   HIP_TRY(b->d_sort_tmp.alloc(b->sort_tmp_bytes + 16));
@@ -1134,9 +1137,9 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   return HNY_OK;
 }
 
-int hny_builder_apply(hny_builder *b, const void *sel_dev) {
-  if (!b || !b->in_batch) return fail(HNY_ERR_INVALID_ARG, "no current batch");
-  HIP_TRY(hipSetDevice(b->device));
+// phase 2 up to and including k_apply: link ops emitted, sorted, segmented; every target whose list
+// cannot overflow is done, the others are listed in d_deferred (first op of their segment)
+static int apply_front(hny_builder *b, const void *sel_dev, ApplyArgs &a) {
   const uint32_t L = b->cur.level, cs = cap_of(b, L);
   const u64 *sel = sel_dev ? (const u64 *)sel_dev : b->d_sel.p;
   const u32 n_ops = b->cur.count * (L + 1) * cs * 2;
@@ -1157,7 +1160,7 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   HIP_TRY(hipMemsetAsync(b->d_nseg.p, 0, 8, b->stream));
   HIP_TRY(hnyk_segments(b->d_keys_b.p, n_ops, b->d_seg_start.p, b->d_nseg.p, b->stream));
   prof_end(b);
-  ApplyArgs a{};
+  a = ApplyArgs{};
   a.keys = b->d_keys_b.p;
   a.vals = b->d_vals_b.p;
   a.n_ops = n_ops;
@@ -1168,14 +1171,96 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
   prof_begin(b, EV_APPLY);
   HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream));
-  if (!b->wave_prune_only)
-    HIP_TRY(hnyk_apply_wg(b->g, a, b->shape, b->stage_rows,
-                          (int)std::min<u32>(std::max<u32>(n_ops / 8, 1), 2048), b->stream));
   prof_end(b);
+  b->cur_n_ops = n_ops;
+  return HNY_OK;
+}
+
+static void apply_back(hny_builder *b) {
   b->pos += b->cur.count;
   b->n_done += b->cur.count;
   b->n_batches++;
   b->in_batch = false;
+  b->apply_open = false;
+}
+
+int hny_builder_apply(hny_builder *b, const void *sel_dev) {
+  if (!b || !b->in_batch || b->apply_open) return fail(HNY_ERR_INVALID_ARG, "no current batch");
+  HIP_TRY(hipSetDevice(b->device));
+  ApplyArgs a;
+  if (int rc = apply_front(b, sel_dev, a)) return rc;
+  if (!b->wave_prune_only) {
+    prof_begin(b, EV_APPLY);
+    HIP_TRY(hnyk_apply_wg(b->g, a, b->shape, b->stage_rows,
+                          (int)std::min<u32>(std::max<u32>(b->cur_n_ops / 8, 1), 2048), b->stream));
+    prof_end(b);
+  }
+  apply_back(b);
+  return HNY_OK;
+}
+
+uint32_t hny_builder_exch_stride_u64(const hny_builder *b) {
+  return b ? 2u + std::max(b->o.M, b->o.M0) : 0u;
+}
+
+int hny_builder_apply_begin(hny_builder *b, const void *sel_dev, uint32_t *n_deferred) {
+  if (!b || !b->in_batch || b->apply_open || !n_deferred) return fail(HNY_ERR_INVALID_ARG, "no current batch");
+  HIP_TRY(hipSetDevice(b->device));
+  ApplyArgs a;
+  if (int rc = apply_front(b, sel_dev, a)) return rc;
+  u32 nd = 0;
+  if (!b->wave_prune_only) {
+    HIP_TRY(hipMemcpyAsync(&nd, b->d_nseg.p + 1, 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (nd > 1) { // canonical order: k_apply appended in atomic order, which differs between replicas
+      HIP_TRY(hnyk_sort_u32(b->d_sort_tmp.p, b->sort_tmp_bytes, b->d_deferred.p, b->d_deferred_b.p, nd, b->stream));
+      HIP_TRY(hipMemcpyAsync(b->d_deferred.p, b->d_deferred_b.p, (size_t)nd * 4, hipMemcpyDeviceToDevice, b->stream));
+    }
+  }
+  b->cur_n_def = nd;
+  b->apply_open = true;
+  *n_deferred = nd;
+  return HNY_OK;
+}
+
+int hny_builder_apply_deferred(hny_builder *b, uint32_t rank, uint32_t world, void *exch_dev) {
+  if (!b || !b->apply_open || world == 0 || rank >= world || (world > 1 && !exch_dev))
+    return fail(HNY_ERR_INVALID_ARG, "hny_builder_apply_deferred: bad argument or no open apply");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->wave_prune_only || b->cur_n_def == 0) return HNY_OK;
+  ApplyArgs a{};
+  a.keys = b->d_keys_b.p;
+  a.vals = b->d_vals_b.p;
+  a.n_ops = b->cur_n_ops;
+  a.seg_start = b->d_seg_start.p;
+  a.n_seg = b->d_nseg.p;
+  a.deferred = b->d_deferred.p;
+  a.n_deferred = b->d_nseg.p + 1;
+  a.shard_rank = rank;
+  a.shard_world = world;
+  a.exch_stride = hny_builder_exch_stride_u64(b);
+  const u32 per = (b->cur_n_def + world - 1) / world;
+  a.exch = world > 1 ? (u64 *)exch_dev + (size_t)rank * per * a.exch_stride : nullptr;
+  prof_begin(b, EV_APPLY);
+  HIP_TRY(hnyk_apply_wg(b->g, a, b->shape, b->stage_rows, (int)std::min<u32>(std::max<u32>(per, 1), 2048),
+                        b->stream));
+  prof_end(b);
+  return HNY_OK;
+}
+
+int hny_builder_apply_merge(hny_builder *b, const void *exch_all_dev, uint32_t rank, uint32_t world) {
+  if (!b || !b->apply_open || world == 0 || rank >= world)
+    return fail(HNY_ERR_INVALID_ARG, "hny_builder_apply_merge: bad argument or no open apply");
+  HIP_TRY(hipSetDevice(b->device));
+  if (world > 1 && b->cur_n_def && !b->wave_prune_only) {
+    if (!exch_all_dev) return fail(HNY_ERR_INVALID_ARG, "hny_builder_apply_merge: null exchange buffer");
+    const u32 per = (b->cur_n_def + world - 1) / world;
+    prof_begin(b, EV_APPLY);
+    HIP_TRY(hnyk_apply_merge(b->g, (const u64 *)exch_all_dev, b->cur_n_def, world, rank, per,
+                             hny_builder_exch_stride_u64(b), b->stream));
+    prof_end(b);
+  }
+  apply_back(b);
   return HNY_OK;
 }
 

@@ -171,8 +171,15 @@ struct ApplyArgs {
   u32 n_ops;
   const u32 *seg_start;
   const u32 *n_seg;
-  u32 *deferred;   // segments whose list may overflow (handled by k_apply_wg); null = do all here
+  u32 *deferred;   // first op of every segment whose list may overflow (handled by k_apply_wg);
+                   // null = k_apply does everything
   u32 *n_deferred;
+  // multi-GPU: k_apply_wg takes deferred[i] with i % shard_world == shard_rank (the list is sorted,
+  // so every rank sees the same order) and also writes the finished list to exch[(i / shard_world)]:
+  // exch_stride u64 words = key (layer << 31 | target), count word, cap x (dist bits << 32 | slot)
+  u32 shard_rank, shard_world;
+  u64 *exch;
+  u32 exch_stride;
 };
 
 struct LaunchShape {
@@ -190,6 +197,9 @@ hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg,
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st);
+hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,
+                            u32 stride, hipStream_t st);
+hipError_t hnyk_sort_u32(void *temp, size_t temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st);
 hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
                          hipStream_t st);
 hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,

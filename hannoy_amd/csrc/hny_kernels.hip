@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
         if (cnt + (int)nops > (int)cap) break;
       }
       if (cnt + (int)nops > (int)cap) {
-        if (ln == 0) a.deferred[atomicAdd(a.n_deferred, 1u)] = sg;
+        if (ln == 0) a.deferred[atomicAdd(a.n_deferred, 1u)] = i0;
         continue;
       }
     }
@@ -1893,9 +1893,9 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
   const int tid = threadIdx.x;
   const u32 n_def = *a.n_deferred;
   u64 evals = 0;
-  for (u32 di = blockIdx.x; di < n_def; di += gridDim.x) {
-    const u32 sg = a.deferred[di];
-    const u32 i0 = a.seg_start[sg];
+  const u32 sw = a.shard_world ? a.shard_world : 1u;
+  for (u32 di = a.shard_rank + blockIdx.x * sw; di < n_def; di += gridDim.x * sw) {
+    const u32 i0 = a.deferred[di];
     const u64 k0 = a.keys[i0] >> HNY_SEQ_BITS;
     const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
     u32 cap, *ids, *cntp;
@@ -1950,9 +1950,54 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
       dist[tid] = on ? __uint_as_float((u32)(lk[tid] >> 32)) : 0.f;
     }
     if (tid == 0) *cntp = (u32)cnt | (frozen ? 0x80000000u : 0u);
+    if (a.exch) { // the finished list, for the ranks that did not compute it
+      u64 *rec = a.exch + (size_t)(di / sw) * a.exch_stride;
+      if (tid == 0) {
+        rec[0] = k0;
+        rec[1] = (u64)((u32)cnt | (frozen ? 0x80000000u : 0u));
+      }
+      if (tid < cnt) rec[2 + tid] = lk[tid];
+    }
     __syncthreads();
   }
   if ((tid & 63) == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
+}
+
+// multi-GPU: the lists other ranks finished in their share of the deferred segments (k_apply_wg's
+// exch records, all-gathered) written into this rank's replica.  One wave per record.
+__global__ __launch_bounds__(64) void k_apply_merge(GraphDev g, const u64 *exch, u32 n_def, u32 world, u32 rank,
+                                                    u32 per, u32 stride) {
+  const int ln = threadIdx.x;
+  for (u32 di = blockIdx.x; di < n_def; di += gridDim.x) {
+    const u32 owner = di % world;
+    if (owner == rank) continue;
+    const u64 *rec = exch + ((size_t)owner * per + di / world) * stride;
+    const u64 k0 = rec[0];
+    const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
+    const u32 cw = (u32)rec[1];
+    const int cnt = (int)(cw & 0xFFFFu);
+    u32 cap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)target * g.M0;
+      dist = g.l0_dist + (size_t)target * g.M0;
+      cntp = g.l0_cnt + target;
+    } else {
+      size_t u = (size_t)g.upper_idx[target] * g.up_layers + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    if ((u32)ln < cap) {
+      const bool on = ln < cnt;
+      const u64 e = on ? rec[2 + ln] : 0ull;
+      ids[ln] = on ? (u32)(e & 0xFFFFFFFFull) : HNY_SENT;
+      dist[ln] = on ? __uint_as_float((u32)(e >> 32)) : 0.f;
+    }
+    if (ln == 0) *cntp = cw;
+  }
 }
 
 // fill_gaps_from_deleted (hnsw.rs:334-415), one wave per surviving old record (layer, slot):
@@ -2477,6 +2522,16 @@ hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *ke
                            u64 *vals_out, u32 n, hipStream_t st) {
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
                                    0, 64, st);
+}
+hipError_t hnyk_sort_u32(void *temp, size_t temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st) {
+  return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, 32, st);
+}
+hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,
+                            u32 stride, hipStream_t st) {
+  if (!n_def || world < 2) return hipSuccess;
+  hipLaunchKernelGGL(k_apply_merge, dim3(std::min<u32>(n_def, 8192u)), dim3(64), 0, st, g, exch, n_def, world,
+                     rank, per, stride);
+  return hipGetLastError();
 }
 hipError_t hnyk_sort_pairs48(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
                              u64 *vals_out, u32 n, hipStream_t st) {

@@ -3,15 +3,19 @@ replica of the vectors and of the graph in HBM.  Per batch each rank runs walk_l
 (hny_builder_search) for its contiguous slice of the batch members against the frozen graph, the
 fixed-size selection records are exchanged with ONE all-gather (RCCL over xGMI, `nccl` backend),
 and every rank applies the same link ops in the same order (hny_builder_apply), which keeps the
-replicas bit-identical without a second collective.  Small batches (the ramp-up) are computed
-redundantly by every rank instead: the exchange would cost more than the search.
+replicas bit-identical.  Most link ops only append to a list and are replayed by every rank; the
+targets whose list overflows re-run robust_prune on it (hnsw.rs:547-552, a third of the apply
+phase's time): those are split across the ranks as well (hny_builder_apply_begin / _deferred /
+_merge) and their finished lists exchanged with a second, small all-gather (272 B per target at
+M0=32, a few MB per batch).  Small batches (the ramp-up) are computed redundantly by every rank
+instead: the exchange would cost more than the search.
 """
 import math
 
 
 class Driver:
     def __init__(self, builder, torch, dist, rank=0, world=1, device=None, min_shard_batch=None,
-                 host_staged=False, force_collective=False):
+                 host_staged=False, force_collective=False, shard_apply=None, min_shard_deferred=None):
         self.b, self.torch, self.dist = builder, torch, dist
         # host_staged: exchange through host memory (gloo); default is device buffers over RCCL
         self.host_staged = host_staged
@@ -19,7 +23,11 @@ class Driver:
         self.rank, self.world, self.device = rank, world, device
         self.min_shard = 64 * world if min_shard_batch is None else min_shard_batch
         self._buf = None
+        self._buf2 = None
         self.n_collectives = 0
+        # shard the deferred re-prunes of the apply phase too (needs the three-step apply of the C ABI)
+        self.shard_apply = hasattr(builder, "apply_begin") if shard_apply is None else shard_apply
+        self.min_shard_deferred = 32 * world if min_shard_deferred is None else min_shard_deferred
 
     def _buffer(self, words):
         if self._buf is None or self._buf.numel() < words:
@@ -61,8 +69,37 @@ class Driver:
                 self.dist.all_gather_into_tensor(full[:self.world * per * stride], mine)
             self.n_collectives += 1
             self._sync_collective()
-            b.apply(full.data_ptr())
+            if not self.shard_apply:
+                b.apply(full.data_ptr())
+                continue
+            nd = b.apply_begin(full.data_ptr())  # the same number on every rank (same inputs)
+            if nd < self.min_shard_deferred:
+                b.apply_deferred(0, 1, None)
+                b.apply_merge(None, 0, 1)
+                continue
+            xs = b.exch_stride_u64
+            per2 = math.ceil(nd / self.world)
+            if self._buf2 is None or self._buf2.numel() < self.world * per2 * xs:
+                self._buf2 = self.torch.empty(self.world * per2 * xs, dtype=self.torch.int64, device=self.device)
+            ex = self._buf2
+            b.apply_deferred(self.rank, self.world, ex.data_ptr())
+            b.sync()
+            self._all_gather(ex, per2 * xs)
+            b.apply_merge(ex.data_ptr(), self.rank, self.world)
         return n
+
+    def _all_gather(self, full, words_per_rank):
+        """in-place all-gather of `full[rank * w : (rank + 1) * w]` (w = words_per_rank)"""
+        w = words_per_rank
+        mine = full[self.rank * w:(self.rank + 1) * w].clone()
+        if self.host_staged:
+            gathered = self.torch.empty(self.world * w, dtype=self.torch.int64)
+            self.dist.all_gather_into_tensor(gathered, mine.cpu())
+            full[:self.world * w].copy_(gathered)
+        else:
+            self.dist.all_gather_into_tensor(full[:self.world * w], mine)
+        self.n_collectives += 1
+        self._sync_collective()
 
     def _sync_collective(self):
         if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":

@@ -165,6 +165,17 @@ int hny_builder_next_batch(hny_builder *b, hny_batch *out);
 int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev);
 /* add_link for every selected pair, both directions (hnsw.rs:316-324, 523-560), in batch order */
 int hny_builder_apply(hny_builder *b, const void *sel_dev);
+/* hny_builder_apply in three steps, for the multi-GPU driver: most targets just append their new
+ * links (cheap, done by every replica in _begin); a target whose list overflows re-runs
+ * robust_prune on it (hnsw.rs:547-552) — these "deferred" targets, n_deferred of them in an order
+ * that is the same on every replica, are split across the ranks by _deferred (rank r takes every
+ * world-th one and writes the finished lists to its part of exch_dev: world * ceil(n_deferred /
+ * world) records of hny_builder_exch_stride_u64 words), the parts are all-gathered by the caller,
+ * and _merge installs the other ranks' lists and closes the batch.  world == 1: exch may be NULL. */
+int hny_builder_apply_begin(hny_builder *b, const void *sel_dev, uint32_t *n_deferred);
+int hny_builder_apply_deferred(hny_builder *b, uint32_t rank, uint32_t world, void *exch_dev);
+int hny_builder_apply_merge(hny_builder *b, const void *exch_all_dev, uint32_t rank, uint32_t world);
+uint32_t hny_builder_exch_stride_u64(const hny_builder *b);
 int hny_builder_sync(hny_builder *b);
 /* record a HIP event pair around every kernel family launch (bench roofline accounting) */
 int hny_builder_set_profiling(hny_builder *b, int on);

@@ -405,6 +405,60 @@ def test_full_size_other_baseline_configs(orc, hny, cfg):
     assert int(cnt.min()) == 10 and np.all(np.diff(dists, axis=1) >= 0)  # drain_asc, k hits each
 
 
+def test_sharded_deferred_prunes_two_replicas(orc, hny):
+    """The multi-GPU apply phase on one GPU: two builders play two ranks.  Each runs the replicated
+    part (hny_builder_apply_begin), re-prunes only its half of the overflowing targets
+    (_apply_deferred, every second one of the canonically ordered list), the halves are exchanged by
+    hand (what the all-gather does) and installed (_apply_merge).  Both replicas must end up with
+    the oracle's graph, and must agree on the number of deferred targets in every batch."""
+    import torch
+    rng = np.random.default_rng(31)
+    n, dim, M, M0, ef = 12000, 96, 8, 16, 48
+    cent = rng.uniform(-1, 1, (24, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 24, n)] + 0.25 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, M, seed=6))
+    kw = dict(M=M, M0=M0, batch_frac=1.0, batch_max=2048)
+    o = orc.build(ds, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    dev = torch.device("cuda", 0)
+    exchanged = 0
+    with hny.Builder(items, ef_construction=ef, **kw) as b0, hny.Builder(items, ef_construction=ef, **kw) as b1:
+        reps = (b0, b1)
+        xs = b0.exch_stride_u64
+        assert xs == 2 + M0
+        while True:
+            bts = [b.next_batch() for b in reps]
+            assert bts[0].count == bts[1].count
+            if bts[0].count == 0:
+                break
+            for b in reps:
+                b.search(0, bts[0].count)
+            nds = [b.apply_begin() for b in reps]
+            assert nds[0] == nds[1]
+            nd = nds[0]
+            if nd < 2:
+                for b in reps:
+                    b.apply_deferred(0, 1, None)
+                    b.apply_merge(None, 0, 1)
+                continue
+            exchanged += 1
+            per = -(-nd // 2)
+            bufs = [torch.full((2 * per * xs,), -1, dtype=torch.int64, device=dev) for _ in reps]
+            for r, b in enumerate(reps):
+                b.apply_deferred(r, 2, bufs[r].data_ptr())
+                b.sync()
+            allb = torch.cat([bufs[0][:per * xs], bufs[1][per * xs:]])  # the all-gather
+            keys = allb.view(2 * per, xs)[:, 0]
+            assert int((keys >= 0).sum()) == nd  # every deferred target was handled by exactly one rank
+            for r, b in enumerate(reps):
+                b.apply_merge(allb.data_ptr(), r, 2)
+                b.sync()
+        g0, g1 = b0.finish(), b1.finish()
+    assert exchanged >= 3
+    _same_graph(g0, o)
+    _same_graph(g1, o)
+    assert g0.n_evals_apply + g1.n_evals_apply >= o.n_evals_apply if hasattr(o, "n_evals_apply") else True
+
+
 def test_rccl_exchange_path_single_rank(orc, hny):
     """The multi-GPU driver's exchange on the real thing: `nccl` (= RCCL) process group with one rank,
     all_gather_into_tensor on the device selection buffer handed to the C ABI, then apply from it.

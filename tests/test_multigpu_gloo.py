@@ -25,6 +25,7 @@ class FakeBuilder:
         self.applied = []
         self.internal = None
         self.search_calls = []
+        self.deferred_calls, self.merged, self.nd = [], [], 0
 
     def next_batch(self):
         if self.i >= len(self.sizes):
@@ -57,6 +58,38 @@ class FakeBuilder:
         self.first += self.cur.count
         self.i += 1
 
+    # three-step apply (hny_builder_apply_begin / _deferred / _merge): a third of the members are
+    # "deferred"; record i of a batch is the pure function g(first, i)
+    exch_stride_u64 = 3
+
+    def apply_begin(self, sel_ptr=None):
+        buf = self._view(sel_ptr, self.cur.count * self.stride)
+        self.applied.append(buf[:self.cur.count * self.stride].clone())
+        self.nd = self.cur.count // 3
+        return self.nd
+
+    def apply_deferred(self, rank=0, world=1, exch_ptr=None):
+        self.deferred_calls.append((self.cur.first, rank, world))
+        if exch_ptr is None:
+            return
+        per = -(-self.nd // world)
+        buf = self._view(exch_ptr, world * per * self.exch_stride_u64)
+        for i in range(rank, self.nd, world):
+            for w in range(self.exch_stride_u64):
+                buf[(rank * per + i // world) * self.exch_stride_u64 + w] = self.cur.first * 7919 + i * 10 + w
+
+    def apply_merge(self, exch_ptr=None, rank=0, world=1):
+        if exch_ptr is not None:
+            per = -(-self.nd // world)
+            buf = self._view(exch_ptr, world * per * self.exch_stride_u64)
+            recs = []
+            for i in range(self.nd):
+                at = ((i % world) * per + i // world) * self.exch_stride_u64
+                recs.append([int(buf[at + w]) for w in range(self.exch_stride_u64)])
+            self.merged.append((self.cur.first, recs))
+        self.first += self.cur.count
+        self.i += 1
+
     def run(self):
         n = 0
         while True:
@@ -83,7 +116,7 @@ def _worker(rank, world, port, q):
     drv = Driver(fb, torch, dist, rank, world, torch.device("cpu"), min_shard_batch=64)
     n = drv.run()
     digest = [t.numpy().tobytes() for t in fb.applied]
-    q.put((rank, n, drv.n_collectives, digest, fb.search_calls))
+    q.put((rank, n, drv.n_collectives, digest, fb.search_calls, fb.merged, fb.deferred_calls))
     dist.destroy_process_group()
 
 
@@ -107,13 +140,21 @@ def test_driver_world2_gloo():
     ref = FakeBuilder(torch, SIZES)
     ref.run()
     want = [t.numpy().tobytes() for t in ref.applied]
-    for rank, n, ncoll, digest, calls in res:
+    first, exp_merged = 0, []
+    for sz in SIZES:  # the deferred share is exchanged when it has >= 32 * world members
+        if sz >= 64 and sz // 3 >= 64:
+            exp_merged.append((first, [[first * 7919 + i * 10 + w for w in range(3)] for i in range(sz // 3)]))
+        first += sz
+    for rank, n, ncoll, digest, calls, merged, dcalls in res:
         assert n == len(SIZES)
         assert digest == want, f"rank {rank} applied different selections"
-        assert ncoll == sum(1 for s_ in SIZES if s_ >= 64)
+        assert ncoll == sum(1 for s_ in SIZES if s_ >= 64) + len(exp_merged)
+        assert merged == exp_merged, f"rank {rank} merged different lists"
+        assert all((r, w) == ((rank, 2) if any(f == m[0] for m in exp_merged) else (0, 1)) for f, r, w in dcalls)
     # each sharded batch was split into disjoint contiguous halves covering it
     c0 = {(f, lo, hi) for f, lo, hi in res[0][4]}
     c1 = {(f, lo, hi) for f, lo, hi in res[1][4]}
+    assert len(exp_merged) >= 2
     first = 0
     for sz in SIZES:
         if sz >= 64:
