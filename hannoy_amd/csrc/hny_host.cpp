@@ -1383,6 +1383,9 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->entry_points = eps;
   g->n_entry_points = (uint32_t)b->entry_points.size();
   g->max_level = ml;
+  if (getenv("HNY_DEBUG_COUNTS"))
+    fprintf(stderr, "[hny] expansions %llu accepted %llu notfull %llu evals_walk %llu\n", stats[9], stats[10], stats[11],
+            stats[ST_EVALS_WALK]);
   g->n_links_added = stats[ST_LINKS];
   g->n_evals_walk = stats[ST_EVALS_WALK];
   g->n_evals_prune = stats[ST_EVALS_PRUNE];

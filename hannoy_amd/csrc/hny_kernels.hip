@@ -32,8 +32,21 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #endif
 
-// block == one wave: with __launch_bounds__(64) the barrier is a wave-level fence only
+// block == one wave (every user of WSYNC is a 64-thread kernel): lanes exchange data through LDS, and
+// the LDS executes one wave's operations in issue order, so all that is needed is that the compiler
+// keeps the order and that pending LDS returns are waited for.  __syncthreads() did that too, but it
+// also drains vmcnt(0) — every row / neighbour-list load in flight — at each of the ~20 syncs of an
+// expansion.
+#ifdef HNY_WSYNC_BARRIER
 #define WSYNC() __syncthreads()
+#else
+#define WSYNC()                                               \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");    \
+  } while (0)
+#endif
 
 namespace {
 
@@ -800,6 +813,9 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       WSYNC();
     }
     const float fmax = __uint_as_float(dmax); // f_max captured once per pop (:484)
+#ifdef HNY_DEBUG_COUNTS
+    if (ln == 0) atomicAdd(&g.stats[9], 1ull);
+#endif
 
     // ---- neighbours of c (:491-495): on-disk Links first (incremental builds, :438-441), then the
     // in-memory list
@@ -851,6 +867,9 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       bool acc = ln < n_new && (ln < room || myd < fmax);
       u64 amask = __ballot(acc);
       WSYNC();
+#ifdef HNY_DEBUG_COUNTS
+      if (ln == 0) { atomicAdd(&g.stats[10], (u64)__popcll(amask)); atomicAdd(&g.stats[11], (u64)(s.res_len < ef ? 1 : 0)); }
+#endif
       while (amask) {
         int r = __ffsll((long long)amask) - 1;
         amask &= amask - 1ull;
