@@ -185,7 +185,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
     # the figure comes from the committed rocprofv3 --pmc passes of this same command
     # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch
-    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_bm65536.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_specialised.json")
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
                   and world == 1 and not a.x86_order)
@@ -195,19 +195,23 @@ def main():
         if pk:
             total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
             roof["traffic"] = int(total / max(1, pk["launches"]))
-            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_bm65536.json: rocprofv3 --pmc FETCH_SIZE / "
+            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_specialised.json: rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes of this command (scripts/profile_c2.sh), 2x FETCH + "
                                       f"WRITE summed over the {pk['launches']} k_walk dispatches of one build, "
                                       "per dispatch; FETCH_SIZE counts Infinity-Cache hits too, so this is "
                                       "L2-to-fabric traffic, an upper bound on HBM")
 
+    known = {(1_000_000, 768, "cosine", 16, 100): "C2", (1_000_000, 768, "euclidean", 32, 200): "C3",
+             (10_000_000, 128, "cosine", 16, 100): "C4 (on %d GPU)" % world,
+             (5_000_000, 1024, "hamming", 16, 64): "C5 (on %d GPU)" % world}
+    cfg_name = known.get((a.n, a.dim, a.metric, a.M, a.ef), "custom")
     out = {
         "metric": "vectors indexed/sec (build) + recall@10, 1M x 768 Cosine M=16 efC=100",
         "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / max(1, a.steps), 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if metric < H.HAMMING else "u64-popcount", "data": "synthetic",
-        "config": {"workload": f"C2: {a.n} x {a.dim} {a.metric}, M={a.M} M0={M0} efC={a.ef}, "
+        "config": {"workload": f"{cfg_name}: {a.n} x {a.dim} {a.metric}, M={a.M} M0={M0} efC={a.ef}, "
                                f"{a.data} synthetic vectors resident in HBM, 1 step = 1 full build",
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
                    "batch_frac": builder.opts.batch_frac or 1.0,
