@@ -586,6 +586,58 @@ __device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
   beam_evicted(s, oldmax, nd);
 }
 
+// ---- the same beam held in REGISTERS (RB kernels: rows <= 2 KB, ef <= 127, <= 64 entry points).
+// On short rows the walk is bound by instruction issue, not by bytes: two thirds of its
+// instructions are beam / visited bookkeeping, and every res access above is an LDS round trip plus
+// address arithmetic.  Entry e of the sorted array lives in lane e % 64 of r0 (e < 64) or r1; an
+// insertion is a ballot rank and a one-lane DPP shift, a pop is a ballot on the expanded bits.
+struct BeamR {
+  u64 r0, r1;
+};
+__device__ __forceinline__ u64 rb_get(const BeamR &r, int e) { // e: wave-uniform index
+  const u64 v = e < 64 ? r.r0 : r.r1;
+  const int l = e & 63;
+  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+  const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+// lane l <- lane l - 1 (v_mov_b32_dpp wave_shr:1), lane 0 <- `lane0`
+__device__ __forceinline__ u64 rb_shift_up(u64 v, u64 lane0) {
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)lane0, (int)(u32)v, 0x138, 0xf, 0xf, false);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(lane0 >> 32), (int)(u32)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((u64)hi << 32) | lo;
+}
+// beam_insert on the register beam: identical outcome (same res, pool, tie_bits, dropped)
+__device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR &r, u64 key, int ef) {
+  const int ln = threadIdx.x;
+  const int len = s.res_len;
+  const int pos = __popcll(__ballot(ln < len && (r.r0 & ~1ull) < key)) +
+                  __popcll(__ballot(ln + 64 < len && (r.r1 & ~1ull) < key));
+  const bool evict = (len == ef);
+  const u64 oldmax = len ? rb_get(r, len - 1) : 0ull;
+  if (evict && pos == len) { // the new entry is the max: pushed and popped at once
+    beam_evicted(s, key, (u32)(oldmax >> 32));
+    return;
+  }
+  if (!evict && len >= s.rcap) {
+    s.err = 1;
+    return;
+  }
+  const int hi = evict ? len - 1 : len; // indices (pos, hi] take the entry below them
+  const u64 carry = rb_get(r, 63);
+  const u64 up0 = rb_shift_up(r.r0, 0ull), up1 = rb_shift_up(r.r1, carry);
+  const int e0 = ln, e1 = ln + 64;
+  r.r0 = e0 == pos ? key : ((e0 > pos && e0 <= hi) ? up0 : r.r0);
+  r.r1 = e1 == pos ? key : ((e1 > pos && e1 <= hi) ? up1 : r.r1);
+  if (!evict) {
+    s.res_len = len + 1;
+    return;
+  }
+  const u32 nd = (u32)(rb_get(r, len - 1) >> 32);
+  if (s.pool_len - s.n_weird > 0 && s.tie_bits != nd) pool_drop_ties(s);
+  beam_evicted(s, oldmax, nd);
+}
+
 // visited set of one query (RoaringBitmap `visited`, hnsw.rs:471 / `path`, reader.rs:726).  First
 // level: an open-addressing hash table in LDS (a query marks ~1e3 of the N items, so a per-wave
 // N-bit set in HBM costs one scattered L2 atomic per neighbour looked at and a dirty 128-B line per
@@ -701,11 +753,12 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 }
 
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
-template <int LPR, int NCH, bool BIG_EPS>
+template <int LPR, int NCH, bool BIG_EPS, bool RB = false>
 __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
-                               const unsigned char *qrow) {
+                               const unsigned char *qrow, BeamR &rb) {
+  static_assert(!(RB && BIG_EPS), "the register beam holds at most 128 entries");
   const int ln = threadIdx.x;
   s.res_len = 0;
   s.pool_len = 0;
@@ -731,7 +784,8 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     WSYNC();
     for (int r = 0; r < ne; r++) {
       u64 key = ((u64)uni(fbits(nb_d[r])) << 32) | ((u64)uni(nb_ids[r]) << 1);
-      beam_insert(s, key, 0x7FFFFFFF);
+      if constexpr (RB) beam_insert_rb(s, rb, key, 0x7FFFFFFF);
+      else beam_insert(s, key, 0x7FFFFFFF);
     }
   }
   for (u32 iter = 0;; iter++) {
@@ -741,7 +795,23 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     }
     // ---- candidates.peek()/pop(): smallest distance bits, larger id first among equals
     // (BinaryHeap<(Reverse<OrderedFloat>, ItemId)>, :469, :483-488)
-    int first_un = -1;
+    int first_un = -1, last = -1;
+    u32 dmax;
+    u64 ta = ~0ull;
+    if constexpr (RB) {
+      const int len = s.res_len;
+      const bool un0 = ln < len && !(rb.r0 & 1ull), un1 = ln + 64 < len && !(rb.r1 & 1ull);
+      const u64 m0 = __ballot(un0), m1 = __ballot(un1);
+      first_un = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : -1);
+      dmax = (u32)(rb_get(rb, len - 1) >> 32);
+      last = first_un;
+      if (first_un >= 0) { // pop-order key: distance bits ascending, then id DESCENDING
+        const u32 d0 = (u32)(rb_get(rb, first_un) >> 32);
+        const u64 t0 = __ballot(un0 && (u32)(rb.r0 >> 32) == d0), t1 = __ballot(un1 && (u32)(rb.r1 >> 32) == d0);
+        last = t1 ? 127 - __clzll((long long)t1) : 63 - __clzll((long long)t0);
+        ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get(rb, last) & 0xFFFFFFFEull));
+      }
+    } else {
     for (int base = 0; base < s.res_len; base += 64) {
       int e = base + ln;
       bool un = e < s.res_len && !(s.res[e] & 1ull);
@@ -751,10 +821,9 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         break;
       }
     }
-    const u32 dmax = uni((u32)(s.res[s.res_len - 1] >> 32));
+    dmax = uni((u32)(s.res[s.res_len - 1] >> 32));
     // pop-order key: distance bits ascending, then id DESCENDING
-    u64 ta = ~0ull;
-    int last = first_un;
+    last = first_un;
     if (first_un >= 0) {
       const u32 d0 = uni((u32)(s.res[first_un] >> 32));
       for (int base = first_un & ~63; base < s.res_len; base += 64) {
@@ -766,6 +835,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         if (uni((u32)(s.res[ce] >> 32)) != d0) break;
       }
       ta = ((u64)d0 << 32) | (u64)(~uni((u32)(s.res[last] & 0xFFFFFFFEull)));
+    }
     }
     u64 tp = ~0ull;
     int pi = -1;
@@ -806,6 +876,10 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       s.pool_len--;
       if (weird_bits(fb)) s.n_weird--;
       WSYNC();
+    } else if constexpr (RB) {
+      cslot = (u32)(rb_get(rb, last) >> 1) & 0x7FFFFFFFu;
+      rb.r0 |= (u64)(ln == last);
+      rb.r1 |= (u64)(ln + 64 == last);
     } else {
       cslot = uni((u32)(s.res[last] >> 1) & 0x7FFFFFFFu);
       WSYNC();
@@ -875,7 +949,8 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         amask &= amask - 1ull;
         u32 db = (u32)__builtin_amdgcn_readlane((int)fbits(myd), r);
         u32 idr = (u32)__builtin_amdgcn_readlane((int)myid, r);
-        beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
+        if constexpr (RB) beam_insert_rb(s, rb, ((u64)db << 32) | ((u64)idr << 1), ef);
+        else beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
       }
     }
   }
@@ -890,8 +965,9 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 5
 #endif
-template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false>
+template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, bool RB = false>
 __global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+  static_assert(!(RB && (RM || BIG_EPS || SP == 0)), "register beam: specialised build kernels only");
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
@@ -915,6 +991,9 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY
   s.n_weird = 0;
   s.tie_bits = 0;
   s.dropped = false;
+  BeamR rb;
+  rb.r0 = 0ull;
+  rb.r1 = 0ull;
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u), a.vis_slots);
@@ -967,11 +1046,11 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH, BIG_EPS>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
-                               nb_d, evals, err_iter, qrow);
+      walk_one_layer<LPR, NCH, BIG_EPS, RB>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+                                   nb_d, evals, err_iter, qrow, rb);
       if (last) break;
       // :305-306 eps = [closest]
-      const u32 closest = uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
+      const u32 closest = RB ? (u32)(rb_get(rb, 0) >> 1) & 0x7FFFFFFFu : uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
       if (ln == 0) eps[0] = closest;
       n_eps = 1;
       // locality key: the closest node of the last three greedy layers, coarse to fine
@@ -993,9 +1072,16 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY
       continue;
     }
     // result, ascending (res.into_vec() is re-sorted by robust_prune anyway, :573)
-    for (int e = ln; e < s.res_len; e += 64) {
-      u64 k = s.res[e];
-      a.cand[(size_t)m * a.rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+    if constexpr (RB) {
+      if (ln < s.res_len)
+        a.cand[(size_t)m * a.rcap + ln] = (rb.r0 & 0xFFFFFFFF00000000ull) | ((rb.r0 >> 1) & 0x7FFFFFFFull);
+      if (ln + 64 < s.res_len)
+        a.cand[(size_t)m * a.rcap + 64 + ln] = (rb.r1 & 0xFFFFFFFF00000000ull) | ((rb.r1 >> 1) & 0x7FFFFFFFull);
+    } else {
+      for (int e = ln; e < s.res_len; e += 64) {
+        u64 k = s.res[e];
+        a.cand[(size_t)m * a.rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+      }
     }
     int total = s.res_len;
     if (a.reader_mode && total < (int)a.knn_k) {
@@ -1027,7 +1113,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
+        walk_one_layer<LPR, NCH, BIG_EPS>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
@@ -1264,6 +1350,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
   s.n_weird = 0;
   s.tie_bits = 0;
   s.dropped = false;
+  BeamR rb_unused{0ull, 0ull};
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + a.eps_cap, a.vis_slots);
@@ -1304,7 +1391,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
       for (int i = ln; i < n_eps; i += 64) eps[i] = a.entry_points[i];
       WSYNC();
       for (u32 layer = g.max_level; layer >= 1u; layer--) {
-        walk_one_layer<LPR, NCH, true>(g, q, qn, layer, 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, qrow);
+        walk_one_layer<LPR, NCH, true>(g, q, qn, layer, 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb_unused);
         const u32 closest = uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
         WSYNC();
         if (ln == 0) eps[0] = closest;
@@ -2328,6 +2415,13 @@ struct Hot {
         if (a.reader_mode) {
           hipLaunchKernelGGL((k_walk<L, C, false, SP, true>), dim3(grid), dim3(64), lds, st, g, a);
           return hipGetLastError();
+        }
+        if constexpr (C <= 2) { // short rows: beam in registers (res <= 128 entries)
+          const char *e = getenv("HNY_NO_RB"); // read per launch: tests flip it inside one process
+          if (a.rcap <= 128 && !(e && atoi(e) != 0)) {
+            hipLaunchKernelGGL((k_walk<L, C, false, SP, false, true>), dim3(grid), dim3(64), lds, st, g, a);
+            return hipGetLastError();
+          }
         }
       }
       hipLaunchKernelGGL((k_walk<L, C, false, SP>), dim3(grid), dim3(64), lds, st, g, a);
