@@ -785,9 +785,9 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   }
   if (b->max_ops >= (1ull << HNY_SEQ_BITS))
     return fail(HNY_ERR_UNSUPPORTED, "batch_max too large: %zu link ops per batch >= 2^%d", b->max_ops, HNY_SEQ_BITS);
-  // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (5 for rows <= 1 KB, see k_walk)
+  // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (5 for binary codes <= 1 KB, see k_walk)
   b->walk_slots = (uint32_t)std::min<int64_t>(
-      std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 ? 5120 : 4096)), 65536);
+      std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 && o.metric >= HNY_HAMMING ? 5120 : 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
   b->vis_slots_env = env_int("HNY_VIS_SLOTS", -1);

@@ -48,6 +48,13 @@
   } while (0)
 #endif
 
+#ifndef HNY_RB_MERGE
+#define HNY_RB_MERGE 1
+#endif
+#ifndef HNY_RB_MERGE_MIN
+#define HNY_RB_MERGE_MIN 2
+#endif
+
 namespace {
 
 __device__ __forceinline__ u32 fbits(float f) { return __float_as_uint(f); }
@@ -638,6 +645,84 @@ __device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR &r, u64 key, int e
   beam_evicted(s, oldmax, nd);
 }
 
+// All accepted neighbours of one expansion merged into the register beam at once.  The outcome of
+// the reference's sequence of push / push_pop_max calls (hnsw.rs:508-512) does not depend on their
+// order: res ends up as the new_len smallest keys of (res U accepted); an unexpanded entry that
+// falls out stays poppable only while its distance ties the final res.max (tie pool) or is "weird",
+// and otherwise can never be popped before the walk breaks (`dropped`) — exactly what the
+// one-at-a-time beam_insert leaves behind (pool_drop_ties when the max moves on, beam_evicted per
+// evicted entry).  One rank loop over the accepted keys (a ballot per key), one scatter through the
+// LDS array that the LDS beam would occupy, one classification of what fell out: ~25 instructions
+// per accepted key + ~110, against ~170 per key for sequential inserts (2.8 keys per expansion).
+__device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR &r, bool acc, u64 key, int ef) {
+  const int ln = threadIdx.x;
+  const int len = s.res_len;
+  u64 m = __ballot(acc);
+  const int A = __popcll(m);
+  const u64 k0 = r.r0 & ~1ull, k1 = r.r1 & ~1ull;
+  const bool in0 = ln < len, in1 = ln + 64 < len;
+  int sh0 = 0, sh1 = 0, mypos = 0; // accepted keys below my two res entries / final index of my key
+  while (m) {
+    const int i = __ffsll((long long)m) - 1;
+    m &= m - 1ull;
+    const u64 ki = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(key >> 32), i) << 32) |
+                   (u64)(u32)__builtin_amdgcn_readlane((int)(u32)key, i);
+    const bool l0 = in0 && k0 < ki, l1 = in1 && k1 < ki; // keys are distinct (one slot, one key)
+    const int below = __popcll(__ballot(l0)) + __popcll(__ballot(l1));
+    sh0 += (in0 && !l0) ? 1 : 0;
+    sh1 += (in1 && !l1) ? 1 : 0;
+    mypos += (acc && ki < key) ? 1 : 0;
+    if (ln == i) mypos += below;
+  }
+  const int total = len + A;
+  // push while len != ef, push_pop_max at len == ef; a res that starts above ef (entry points are
+  // pushed without a capacity check, :474-481) only grows
+  const int new_len = len > ef ? total : (total < ef ? total : ef);
+  if (new_len > s.rcap) {
+    s.err = 1;
+    return;
+  }
+  const int i0 = ln + sh0, i1 = ln + 64 + sh1;
+  u64 *st = s.res;
+  if (in0 && i0 < new_len) st[i0] = r.r0;
+  if (in1 && i1 < new_len) st[i1] = r.r1;
+  if (acc && mypos < new_len) st[mypos] = key;
+  WSYNC();
+  const u64 o0 = r.r0, o1 = r.r1;
+  r.r0 = ln < new_len ? st[ln] : 0ull;
+  r.r1 = ln + 64 < new_len ? st[ln + 64] : 0ull;
+  WSYNC();
+  s.res_len = new_len;
+  if (total == new_len) return; // nothing fell out
+  const u32 nd = (u32)(rb_get(r, new_len - 1) >> 32);
+  if (s.pool_len - s.n_weird > 0 && s.tie_bits != nd) pool_drop_ties(s);
+  const u64 lt = (1ull << ln) - 1ull;
+#pragma unroll
+  for (int round = 0; round < 3; round++) {
+    const bool ev = round == 0 ? (in0 && i0 >= new_len) : (round == 1 ? (in1 && i1 >= new_len) : (acc && mypos >= new_len));
+    const u64 x = round == 0 ? o0 : (round == 1 ? o1 : key);
+    const u32 xb = (u32)(x >> 32);
+    const bool un = ev && !(x & 1ull); // already popped from `candidates`: nothing to keep
+    const bool w = weird_bits(xb);
+    const bool keep = un && (w || xb == nd);
+    if (__ballot(un && !w && xb != nd)) s.dropped = true;
+    const u64 pm = __ballot(keep);
+    if (pm) {
+      if (__ballot(keep && !w)) s.tie_bits = nd;
+      int room = HNY_POOL_CAP - s.pool_len;
+      if (room < 0) room = 0;
+      const int rank = __popcll(pm & lt);
+      const bool put = keep && rank < room;
+      if (put) s.pool[s.pool_len + rank] = x & ~1ull;
+      const int np = __popcll(pm), nput = np < room ? np : room;
+      s.n_weird += __popcll(__ballot(put && w));
+      s.pool_len += nput;
+      s.pool_over += (u32)(np - nput);
+      WSYNC();
+    }
+  }
+}
+
 // visited set of one query (RoaringBitmap `visited`, hnsw.rs:471 / `path`, reader.rs:726).  First
 // level: an open-addressing hash table in LDS (a query marks ~1e3 of the N items, so a per-wave
 // N-bit set in HBM costs one scattered L2 atomic per neighbour looked at and a dirty 128-B line per
@@ -941,6 +1026,12 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       bool acc = ln < n_new && (ln < room || myd < fmax);
       u64 amask = __ballot(acc);
       WSYNC();
+      if constexpr (RB) {
+        if (__popcll(amask) >= HNY_RB_MERGE_MIN && HNY_RB_MERGE) { // one key: the plain insert is cheaper
+          beam_merge_rb(s, rb, acc, ((u64)fbits(myd) << 32) | ((u64)myid << 1), ef);
+          amask = 0ull;
+        }
+      }
 #ifdef HNY_DEBUG_COUNTS
       if (ln == 0) { atomicAdd(&g.stats[10], (u64)__popcll(amask)); atomicAdd(&g.stats[11], (u64)(s.res_len < ef ? 1 : 0)); }
 #endif
@@ -959,14 +1050,15 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE
 #define HNY_WALK_WPE 4
 #endif
-// rows of at most 1 KB (NCH == 1; no LDS visited table there, so LDS allows it): the specialised
-// kernels need <= 96 VGPRs and run 5 waves per SIMD (Hamming 1024-bit: walk 0.344 -> 0.310 s; 6
-// would spill).  The general kernels already spill at 4.
+// binary codes of at most 1 KB (NCH == 1; no LDS visited table there, so LDS allows it): the
+// specialised kernels fit ~96 VGPRs and run 5 waves per SIMD (Hamming 1024-bit: walk 0.344 ->
+// 0.310 s; 6 would spill).  The f32 kernels of that row size spill 22 VGPRs at 96 and gain nothing
+// from the fifth wave; the general kernels already spill at 4.
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 5
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, bool RB = false>
-__global__ __launch_bounds__(64, (NCH == 1 && SP != 0 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
   static_assert(!(RB && (RM || BIG_EPS || SP == 0)), "register beam: specialised build kernels only");
   GraphDev g = g_in;
   WalkArgs a = a_in;

@@ -652,11 +652,13 @@ def test_lds_visited_table_and_spill_equal_oracle(orc, hny, slots, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"HNY_OVERLAP": "1"}, {"HNY_PRUNE_NW": "8"}, {"HNY_NO_LOCALITY": "1"},
-                                 {"HNY_STAGE_BYTES": "0"}, {"HNY_STAGE_BYTES": "8192", "HNY_PRUNE_NW": "8"}])
+                                 {"HNY_STAGE_BYTES": "0"}, {"HNY_STAGE_BYTES": "8192", "HNY_PRUNE_NW": "8"},
+                                 {"HNY_NO_RB": "1"}, {"HNY_NO_FAST": "1"}])
 def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
     """Every measured-and-rejected variant that is still selectable by environment (DESIGN.md "what
     did not pay") must build the oracle's graph too: overlapped chunked prune, 8-wave prune chunks,
-    no locality order, no / small LDS stage."""
+    no locality order, no / small LDS stage; and the LDS beam (HNY_NO_RB) / the general kernels
+    (HNY_NO_FAST) where the register beam / the specialised kernels are the default (256-d rows)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(5)
