@@ -333,16 +333,10 @@ def make_opts(metric, dim, M=16, M0=32, ef_construction=100, alpha=1.0, seed=42,
 class Graph:
     """Host copy of hny_graph (records the write loop of hnsw.rs:195-213 consumes)."""
 
+    _ARRAYS = ("rec_item", "rec_layer", "offsets", "nbrs", "entry_points")
+
     def __init__(self, gp, opts=None, items=None):
         g = gp.contents
-        nrec = g.n_records
-        self.rec_item = np.ctypeslib.as_array(g.rec_item, (max(nrec, 1),))[:nrec].copy()
-        self.rec_layer = np.ctypeslib.as_array(g.rec_layer, (max(nrec, 1),))[:nrec].copy()
-        self.offsets = np.ctypeslib.as_array(g.rec_offset, (nrec + 1,)).copy()
-        nl = int(self.offsets[-1])
-        self.nbrs = np.ctypeslib.as_array(g.neighbours, (max(nl, 1),))[:nl].copy()
-        ne = g.n_entry_points
-        self.entry_points = np.ctypeslib.as_array(g.entry_points, (max(ne, 1),))[:ne].copy()
         self.max_level = g.max_level
         for f in ("n_links_added", "n_distance_evals", "n_evals_walk", "n_evals_prune",
                   "n_evals_apply", "n_batches", "t_upload_s", "t_build_s", "t_export_s",
@@ -350,6 +344,28 @@ class Graph:
                   "t_sort_kernels_s", "t_apply_kernels_s", "n_walk_launches"):
             setattr(self, f, getattr(g, f))
         self._gp, self._opts, self._items = gp, opts, items
+
+    def __getattr__(self, name):
+        # numpy copies of the library-owned arrays, made on first use (a 1M x 768 index has 125 MB
+        # of them; the product is the hny_graph itself, these are for tests and scripts)
+        if name not in Graph._ARRAYS or self.__dict__.get("_gp") is None:
+            raise AttributeError(name)
+        g = self._gp.contents
+        nrec = g.n_records
+        if name == "rec_item":
+            v = np.ctypeslib.as_array(g.rec_item, (max(nrec, 1),))[:nrec].copy()
+        elif name == "rec_layer":
+            v = np.ctypeslib.as_array(g.rec_layer, (max(nrec, 1),))[:nrec].copy()
+        elif name == "offsets":
+            v = np.ctypeslib.as_array(g.rec_offset, (nrec + 1,)).copy()
+        elif name == "nbrs":
+            nl = int(self.offsets[-1])
+            v = np.ctypeslib.as_array(g.neighbours, (max(nl, 1),))[:nl].copy()
+        else:
+            ne = g.n_entry_points
+            v = np.ctypeslib.as_array(g.entry_points, (max(ne, 1),))[:ne].copy()
+        self.__dict__[name] = v
+        return v
 
     def __del__(self):
         try:

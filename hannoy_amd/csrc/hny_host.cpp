@@ -1310,15 +1310,15 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
     HIP_TRY(hnyk_finalize_lists(b->d_up_ids.p, b->d_fin_cntu.p, (u32)nup, M, b->stream));
     b->finalized = true;
   }
-  if (n) {
-    HIP_TRY(hipMemcpyAsync(b->h_l0, b->d_l0_ids.p, (size_t)n * M0 * 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipMemcpyAsync(b->h_cnt0, b->d_fin_cnt0.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
-  }
-  if (nup) {
-    HIP_TRY(hipMemcpyAsync(b->h_up, b->d_up_ids.p, nup * M * 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipMemcpyAsync(b->h_cntu, b->d_fin_cntu.p, nup * 4, hipMemcpyDeviceToHost, b->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  // the counts first (small), then the lists (128 MB at C2): the record offsets are computed on the
+  // host while the lists are still in flight
+  if (n) HIP_TRY(hipMemcpyAsync(b->h_cnt0, b->d_fin_cnt0.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+  if (nup) HIP_TRY(hipMemcpyAsync(b->h_cntu, b->d_fin_cntu.p, nup * 4, hipMemcpyDeviceToHost, b->stream));
+  hipEvent_t ev_counts;
+  HIP_TRY(next_sync_event(b, &ev_counts));
+  HIP_TRY(hipEventRecord(ev_counts, b->stream));
+  if (n) HIP_TRY(hipMemcpyAsync(b->h_l0, b->d_l0_ids.p, (size_t)n * M0 * 4, hipMemcpyDeviceToHost, b->stream));
+  if (nup) HIP_TRY(hipMemcpyAsync(b->h_up, b->d_up_ids.p, nup * M * 4, hipMemcpyDeviceToHost, b->stream));
   const u32 *l0 = b->h_l0, *up = b->h_up;
 
   // every inserted item owns a (possibly empty) record on layers 0..=level (add_in_layers_below,
@@ -1339,6 +1339,7 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   uint8_t *rec_layer = (uint8_t *)malloc(std::max<uint64_t>(nrec, 1));
   uint64_t *rec_off = (uint64_t *)malloc((nrec + 1) * 8);
   rec_off[0] = 0;
+  HIP_TRY(hipEventSynchronize(ev_counts));
   for (uint32_t s = 0; s < n; s++) { // offsets: sequential prefix over the device-computed counts
     uint64_t r = rec_first[s];
     for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++) {
@@ -1349,6 +1350,7 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
     }
   }
   uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
+  HIP_TRY(hipStreamSynchronize(b->stream)); // the lists have arrived
   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (n < 10000) nt = 1;
   auto work = [&](uint32_t lo, uint32_t hi) {
