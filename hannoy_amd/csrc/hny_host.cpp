@@ -865,8 +865,31 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_eps0.alloc(cand_rows));
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(b->d_deferred_b.alloc(b->max_ops));
-  HIP_TRY(hnyk_sort_pairs(nullptr, b->sort_tmp_bytes, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
-                          b->d_vals_b.p, (u32)b->max_ops, st));
+  {
+    // rocPRIM does not check the size of the scratch it is given, and what it needs depends on the
+    // bit range (it picks a different algorithm): take the largest of every variant that is called
+    u32 tbits = 1;
+    while ((1ull << tbits) < (u64)b->n + 1ull) tbits++;
+    const u32 ranges[3][2] = {{0, 64}, {HNY_SEQ_BITS, 64}, {HNY_SEQ_BITS, (u32)HNY_SEQ_BITS + tbits}};
+    b->sort_tmp_bytes = 0;
+    // ... and on the number of elements (merge sort below a tuned limit, radix above): probe sizes too
+    for (size_t sz = b->max_ops; sz >= 1; sz = sz > 1 ? sz / 2 : 0) {
+      for (auto &r : ranges) {
+        size_t need = 0;
+        HIP_TRY(hnyk_sort_pairs(nullptr, need, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p, b->d_vals_b.p,
+                                (u32)sz, r[0], r[1], st));
+        b->sort_tmp_bytes = std::max(b->sort_tmp_bytes, need);
+      }
+      size_t need = 0;
+      HIP_TRY(hnyk_sort_pairs48(nullptr, need, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p, b->d_vals_b.p,
+                                (u32)sz, st));
+      b->sort_tmp_bytes = std::max(b->sort_tmp_bytes, need);
+      need = 0;
+      HIP_TRY(hnyk_sort_u32(nullptr, need, b->d_deferred.p, b->d_deferred_b.p, (u32)sz, st));
+      b->sort_tmp_bytes = std::max(b->sort_tmp_bytes, need);
+      if (sz == 1) break;
+    }
+  }
   HIP_TRY(b->d_sort_tmp.alloc(b->sort_tmp_bytes + 16));
 
   g.rows = b->d_rows.p;
@@ -1155,8 +1178,11 @@ static int apply_front(hny_builder *b, const void *sel_dev, ApplyArgs &a) {
   prof_begin(b, EV_SORT);
   HIP_TRY(hnyk_emit(b->g, e, b->stream));
   size_t tmp = b->sort_tmp_bytes;
+  // (sorting only the (layer, target) bits and relying on the stability of the radix sort for the
+  // sequence order — 3 passes instead of 8 — crashed non-deterministically inside the test suite:
+  // rocPRIM switches algorithms with size and bit range; the full 64-bit key is sorted)
   HIP_TRY(hnyk_sort_pairs(b->d_sort_tmp.p, tmp, b->d_keys_a.p, b->d_keys_b.p, b->d_vals_a.p,
-                          b->d_vals_b.p, n_ops, b->stream));
+                          b->d_vals_b.p, n_ops, 0, 64, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_nseg.p, 0, 8, b->stream));
   HIP_TRY(hnyk_segments(b->d_keys_b.p, n_ops, b->d_seg_start.p, b->d_nseg.p, b->stream));
   prof_end(b);
@@ -1213,7 +1239,8 @@ int hny_builder_apply_begin(hny_builder *b, const void *sel_dev, uint32_t *n_def
     HIP_TRY(hipMemcpyAsync(&nd, b->d_nseg.p + 1, 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (nd > 1) { // canonical order: k_apply appended in atomic order, which differs between replicas
-      HIP_TRY(hnyk_sort_u32(b->d_sort_tmp.p, b->sort_tmp_bytes, b->d_deferred.p, b->d_deferred_b.p, nd, b->stream));
+      size_t tmp = b->sort_tmp_bytes;
+      HIP_TRY(hnyk_sort_u32(b->d_sort_tmp.p, tmp, b->d_deferred.p, b->d_deferred_b.p, nd, b->stream));
       HIP_TRY(hipMemcpyAsync(b->d_deferred.p, b->d_deferred_b.p, (size_t)nd * 4, hipMemcpyDeviceToDevice, b->stream));
     }
   }

@@ -199,11 +199,11 @@ hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, i
                          hipStream_t st);
 hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,
                             u32 stride, hipStream_t st);
-hipError_t hnyk_sort_u32(void *temp, size_t temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st);
+hipError_t hnyk_sort_u32(void *temp, size_t &temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st);
 hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,
                          hipStream_t st);
 hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
-                           u64 *vals_out, u32 n, hipStream_t st);
+                           u64 *vals_out, u32 n, u32 begin_bit, u32 end_bit, hipStream_t st);
 hipError_t hnyk_sort_pairs48(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
                              u64 *vals_out, u32 n, hipStream_t st);
 hipError_t hnyk_iota_u64(u64 *p, u32 base, u32 n, hipStream_t st);

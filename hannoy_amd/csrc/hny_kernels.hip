@@ -2724,11 +2724,11 @@ hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t hnyk_sort_pairs(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *keys_out, u64 *vals_in,
-                           u64 *vals_out, u32 n, hipStream_t st) {
+                           u64 *vals_out, u32 n, u32 begin_bit, u32 end_bit, hipStream_t st) {
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
-                                   0, 64, st);
+                                   begin_bit, end_bit, st);
 }
-hipError_t hnyk_sort_u32(void *temp, size_t temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st) {
+hipError_t hnyk_sort_u32(void *temp, size_t &temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st) {
   return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, 32, st);
 }
 hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,
