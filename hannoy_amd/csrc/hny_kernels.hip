@@ -51,6 +51,9 @@
 #ifndef HNY_RB_MERGE
 #define HNY_RB_MERGE 1
 #endif
+#ifndef HNY_RB_MAX_NCH
+#define HNY_RB_MAX_NCH 3
+#endif
 #ifndef HNY_RB_MERGE_MIN
 #define HNY_RB_MERGE_MIN 2
 #endif
@@ -2508,7 +2511,7 @@ struct Hot {
           hipLaunchKernelGGL((k_walk<L, C, false, SP, true>), dim3(grid), dim3(64), lds, st, g, a);
           return hipGetLastError();
         }
-        if constexpr (C <= 2) { // short rows: beam in registers (res <= 128 entries)
+        if constexpr (C <= HNY_RB_MAX_NCH) { // short rows: beam in registers (res <= 128 entries)
           const char *e = getenv("HNY_NO_RB"); // read per launch: tests flip it inside one process
           if (a.rcap <= 128 && !(e && atoi(e) != 0)) {
             hipLaunchKernelGGL((k_walk<L, C, false, SP, false, true>), dim3(grid), dim3(64), lds, st, g, a);
