@@ -1732,8 +1732,8 @@ struct WgPruneLds {
 // LDS) and the chunk is resolved in candidate order — exactly the sequential outcome, with 3
 // barriers per NW candidates.  Each wave streams its next candidate row from HBM one chunk ahead.
 template <int LPR, int NCH, int NW>
-__device__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, const WgPruneLds &L,
-                        u64 &evals) {
+__device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, const WgPruneLds &L,
+                                        u64 &evals) {
   constexpr int RPG = 64 / LPR;
   static_assert(NW == 4 || NW == 8, "chunk of 4 or 8 candidates");
   const int tid = threadIdx.x, w = tid >> 6, ln = tid & 63, t = ln % LPR, sub = ln / LPR;
@@ -1917,7 +1917,21 @@ __global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g_in, PruneArgs a
     const int n = (int)a.cand_n[m];
     for (int e = tid; e < n; e += blockDim.x) list[e] = a.cand[(size_t)m * a.rcap + e];
     __syncthreads();
-    const int s_len = wg_prune<LPR, NCH, NW>(g, list, n, (int)a.cap, L, evals);
+    int s_len;
+    if constexpr (SP != 0) {
+      // rows that fill every lane's chunks (768-d, 1024-d, 128-d, 1024 bits ...): with n16 a
+      // constant the per-chunk bounds guards of the row loads fold away (~20 % of a pass)
+      if (g.n16 == (u32)(LPR * NCH) && g.row_stride == (u32)(LPR * NCH * 16)) {
+        GraphDev gf = g;
+        gf.n16 = (u32)(LPR * NCH);
+        gf.row_stride = (u32)(LPR * NCH * 16);
+        s_len = wg_prune<LPR, NCH, NW>(gf, list, n, (int)a.cap, L, evals);
+      } else {
+        s_len = wg_prune<LPR, NCH, NW>(g, list, n, (int)a.cap, L, evals);
+      }
+    } else {
+      s_len = wg_prune<LPR, NCH, NW>(g, list, n, (int)a.cap, L, evals);
+    }
     u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
     if (tid == 0) out[0] = (u64)s_len;
     if (tid < s_len) out[1 + tid] = L.S[tid];
@@ -2138,7 +2152,15 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
           sorted[rk] = mine;
         }
         __syncthreads();
-        const int s_len = wg_prune<LPR, NCH, 4>(g, sorted, cnt, (int)cap, L, evals);
+        int s_len;
+        if (SP != 0 && g.n16 == (u32)(LPR * NCH) && g.row_stride == (u32)(LPR * NCH * 16)) { // full rows: see k_prune_wg
+          GraphDev gf = g;
+          gf.n16 = (u32)(LPR * NCH);
+          gf.row_stride = (u32)(LPR * NCH * 16);
+          s_len = wg_prune<LPR, NCH, 4>(gf, sorted, cnt, (int)cap, L, evals);
+        } else {
+          s_len = wg_prune<LPR, NCH, 4>(g, sorted, cnt, (int)cap, L, evals);
+        }
         if (tid < s_len) lk[tid] = L.S[tid];
         cnt = s_len;
         frozen = (s_len == (int)cap);
