@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, bool RB = false>
 __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
-  static_assert(!(RB && (RM || BIG_EPS || SP == 0)), "register beam: specialised build kernels only");
+  static_assert(!(RB && (BIG_EPS || SP == 0)), "register beam: specialised kernels only");
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
@@ -1208,14 +1208,21 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        walk_one_layer<LPR, NCH, BIG_EPS, RB>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
         }
-        for (int e = ln; e < s.res_len; e += 64) { // neighbours.extend(more_nns)
-          u64 k = s.res[e];
-          a.cand[(size_t)m * a.rcap + total + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+        if constexpr (RB) { // neighbours.extend(more_nns)
+          if (ln < s.res_len)
+            a.cand[(size_t)m * a.rcap + total + ln] = (rb.r0 & 0xFFFFFFFF00000000ull) | ((rb.r0 >> 1) & 0x7FFFFFFFull);
+          if (ln + 64 < s.res_len)
+            a.cand[(size_t)m * a.rcap + total + 64 + ln] = (rb.r1 & 0xFFFFFFFF00000000ull) | ((rb.r1 >> 1) & 0x7FFFFFFFull);
+        } else {
+          for (int e = ln; e < s.res_len; e += 64) {
+            u64 k = s.res[e];
+            a.cand[(size_t)m * a.rcap + total + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+          }
         }
         total += s.res_len;
         if (total >= (int)a.knn_ef) break; // :792-794
@@ -2529,16 +2536,19 @@ struct Hot {
         }
       }
       if constexpr (SP != 0) {
+        if constexpr (C <= HNY_RB_MAX_NCH) { // beam in registers (res <= 128 entries)
+          const char *e = getenv("HNY_NO_RB"); // read per launch: tests flip it inside one process
+          if (a.rcap <= 128 && !(e && atoi(e) != 0)) {
+            if (a.reader_mode)
+              hipLaunchKernelGGL((k_walk<L, C, false, SP, true, true>), dim3(grid), dim3(64), lds, st, g, a);
+            else
+              hipLaunchKernelGGL((k_walk<L, C, false, SP, false, true>), dim3(grid), dim3(64), lds, st, g, a);
+            return hipGetLastError();
+          }
+        }
         if (a.reader_mode) {
           hipLaunchKernelGGL((k_walk<L, C, false, SP, true>), dim3(grid), dim3(64), lds, st, g, a);
           return hipGetLastError();
-        }
-        if constexpr (C <= HNY_RB_MAX_NCH) { // short rows: beam in registers (res <= 128 entries)
-          const char *e = getenv("HNY_NO_RB"); // read per launch: tests flip it inside one process
-          if (a.rcap <= 128 && !(e && atoi(e) != 0)) {
-            hipLaunchKernelGGL((k_walk<L, C, false, SP, false, true>), dim3(grid), dim3(64), lds, st, g, a);
-            return hipGetLastError();
-          }
         }
       }
       hipLaunchKernelGGL((k_walk<L, C, false, SP>), dim3(grid), dim3(64), lds, st, g, a);
