@@ -601,11 +601,15 @@ __device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
 // instructions are beam / visited bookkeeping, and every res access above is an LDS round trip plus
 // address arithmetic.  Entry e of the sorted array lives in lane e % 64 of r0 (e < 64) or r1; an
 // insertion is a ballot rank and a one-lane DPP shift, a pop is a ballot on the expanded bits.
-struct BeamR {
-  u64 r0, r1;
+template <int RC>
+struct BeamR { // RC x 64 entries: 2 for ef <= 127, 4 for ef <= 255
+  u64 r[RC];
 };
-__device__ __forceinline__ u64 rb_get(const BeamR &r, int e) { // e: wave-uniform index
-  const u64 v = e < 64 ? r.r0 : r.r1;
+template <int RC>
+__device__ __forceinline__ u64 rb_get(const BeamR<RC> &r, int e) { // e: wave-uniform index
+  u64 v = r.r[0];
+#pragma unroll
+  for (int c = 1; c < RC; c++) v = (e >> 6) == c ? r.r[c] : v;
   const int l = e & 63;
   const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
   const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
@@ -618,13 +622,15 @@ __device__ __forceinline__ u64 rb_shift_up(u64 v, u64 lane0) {
   return ((u64)hi << 32) | lo;
 }
 // beam_insert on the register beam: identical outcome (same res, pool, tie_bits, dropped)
-__device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR &r, u64 key, int ef) {
+template <int RC>
+__device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR<RC> &r, u64 key, int ef) {
   const int ln = threadIdx.x;
   const int len = s.res_len;
-  const int pos = __popcll(__ballot(ln < len && (r.r0 & ~1ull) < key)) +
-                  __popcll(__ballot(ln + 64 < len && (r.r1 & ~1ull) < key));
+  int pos = 0;
+#pragma unroll
+  for (int c = 0; c < RC; c++) pos += __popcll(__ballot(ln + 64 * c < len && (r.r[c] & ~1ull) < key));
   const bool evict = (len == ef);
-  const u64 oldmax = len ? rb_get(r, len - 1) : 0ull;
+  const u64 oldmax = len ? rb_get<RC>(r, len - 1) : 0ull;
   if (evict && pos == len) { // the new entry is the max: pushed and popped at once
     beam_evicted(s, key, (u32)(oldmax >> 32));
     return;
@@ -634,16 +640,19 @@ __device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR &r, u64 key, int e
     return;
   }
   const int hi = evict ? len - 1 : len; // indices (pos, hi] take the entry below them
-  const u64 carry = rb_get(r, 63);
-  const u64 up0 = rb_shift_up(r.r0, 0ull), up1 = rb_shift_up(r.r1, carry);
-  const int e0 = ln, e1 = ln + 64;
-  r.r0 = e0 == pos ? key : ((e0 > pos && e0 <= hi) ? up0 : r.r0);
-  r.r1 = e1 == pos ? key : ((e1 > pos && e1 <= hi) ? up1 : r.r1);
+  u64 up[RC];
+#pragma unroll
+  for (int c = 0; c < RC; c++) up[c] = rb_shift_up(r.r[c], c ? rb_get<RC>(r, 64 * c - 1) : 0ull);
+#pragma unroll
+  for (int c = 0; c < RC; c++) {
+    const int e = ln + 64 * c;
+    r.r[c] = e == pos ? key : ((e > pos && e <= hi) ? up[c] : r.r[c]);
+  }
   if (!evict) {
     s.res_len = len + 1;
     return;
   }
-  const u32 nd = (u32)(rb_get(r, len - 1) >> 32);
+  const u32 nd = (u32)(rb_get<RC>(r, len - 1) >> 32);
   if (s.pool_len - s.n_weird > 0 && s.tie_bits != nd) pool_drop_ties(s);
   beam_evicted(s, oldmax, nd);
 }
@@ -657,23 +666,34 @@ __device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR &r, u64 key, int e
 // evicted entry).  One rank loop over the accepted keys (a ballot per key), one scatter through the
 // LDS array that the LDS beam would occupy, one classification of what fell out: ~25 instructions
 // per accepted key + ~110, against ~170 per key for sequential inserts (2.8 keys per expansion).
-__device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR &r, bool acc, u64 key, int ef) {
+template <int RC>
+__device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u64 key, int ef) {
   const int ln = threadIdx.x;
   const int len = s.res_len;
   u64 m = __ballot(acc);
   const int A = __popcll(m);
-  const u64 k0 = r.r0 & ~1ull, k1 = r.r1 & ~1ull;
-  const bool in0 = ln < len, in1 = ln + 64 < len;
-  int sh0 = 0, sh1 = 0, mypos = 0; // accepted keys below my two res entries / final index of my key
+  u64 kc[RC];
+  bool inr[RC];
+  int sh[RC]; // accepted keys below my res entry of chunk c
+#pragma unroll
+  for (int c = 0; c < RC; c++) {
+    kc[c] = r.r[c] & ~1ull;
+    inr[c] = ln + 64 * c < len;
+    sh[c] = 0;
+  }
+  int mypos = 0; // final index of my key
   while (m) {
     const int i = __ffsll((long long)m) - 1;
     m &= m - 1ull;
     const u64 ki = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(key >> 32), i) << 32) |
                    (u64)(u32)__builtin_amdgcn_readlane((int)(u32)key, i);
-    const bool l0 = in0 && k0 < ki, l1 = in1 && k1 < ki; // keys are distinct (one slot, one key)
-    const int below = __popcll(__ballot(l0)) + __popcll(__ballot(l1));
-    sh0 += (in0 && !l0) ? 1 : 0;
-    sh1 += (in1 && !l1) ? 1 : 0;
+    int below = 0;
+#pragma unroll
+    for (int c = 0; c < RC; c++) {
+      const bool l = inr[c] && kc[c] < ki; // keys are distinct (one slot, one key)
+      below += __popcll(__ballot(l));
+      sh[c] += (inr[c] && !l) ? 1 : 0;
+    }
     mypos += (acc && ki < key) ? 1 : 0;
     if (ln == i) mypos += below;
   }
@@ -685,25 +705,30 @@ __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR &r, bool acc, u64 k
     s.err = 1;
     return;
   }
-  const int i0 = ln + sh0, i1 = ln + 64 + sh1;
   u64 *st = s.res;
-  if (in0 && i0 < new_len) st[i0] = r.r0;
-  if (in1 && i1 < new_len) st[i1] = r.r1;
+  int idx[RC];
+  u64 old[RC];
+#pragma unroll
+  for (int c = 0; c < RC; c++) {
+    idx[c] = ln + 64 * c + sh[c];
+    old[c] = r.r[c];
+    if (inr[c] && idx[c] < new_len) st[idx[c]] = r.r[c];
+  }
   if (acc && mypos < new_len) st[mypos] = key;
   WSYNC();
-  const u64 o0 = r.r0, o1 = r.r1;
-  r.r0 = ln < new_len ? st[ln] : 0ull;
-  r.r1 = ln + 64 < new_len ? st[ln + 64] : 0ull;
+#pragma unroll
+  for (int c = 0; c < RC; c++) r.r[c] = ln + 64 * c < new_len ? st[ln + 64 * c] : 0ull;
   WSYNC();
   s.res_len = new_len;
   if (total == new_len) return; // nothing fell out
-  const u32 nd = (u32)(rb_get(r, new_len - 1) >> 32);
+  const u32 nd = (u32)(rb_get<RC>(r, new_len - 1) >> 32);
   if (s.pool_len - s.n_weird > 0 && s.tie_bits != nd) pool_drop_ties(s);
   const u64 lt = (1ull << ln) - 1ull;
 #pragma unroll
-  for (int round = 0; round < 3; round++) {
-    const bool ev = round == 0 ? (in0 && i0 >= new_len) : (round == 1 ? (in1 && i1 >= new_len) : (acc && mypos >= new_len));
-    const u64 x = round == 0 ? o0 : (round == 1 ? o1 : key);
+  for (int round = 0; round <= RC; round++) {
+    const bool ev = round < RC ? (inr[round < RC ? round : 0] && idx[round < RC ? round : 0] >= new_len)
+                               : (acc && mypos >= new_len);
+    const u64 x = round < RC ? old[round < RC ? round : 0] : key;
     const u32 xb = (u32)(x >> 32);
     const bool un = ev && !(x & 1ull); // already popped from `candidates`: nothing to keep
     const bool w = weird_bits(xb);
@@ -841,12 +866,14 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 }
 
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
-template <int LPR, int NCH, bool BIG_EPS, bool RB = false>
+template <int LPR, int NCH, bool BIG_EPS, int RC = 0> // RC: 64-entry chunks of a register beam, 0 = LDS beam
 __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
-                               const unsigned char *qrow, BeamR &rb) {
-  static_assert(!(RB && BIG_EPS), "the register beam holds at most 128 entries");
+                               const unsigned char *qrow, BeamR<(RC ? RC : 1)> &rb) {
+  constexpr bool RB = RC != 0;
+  constexpr int RCN = RC ? RC : 1;
+  static_assert(!(RB && BIG_EPS), "the register beam holds at most 64 * RC entries");
   const int ln = threadIdx.x;
   s.res_len = 0;
   s.pool_len = 0;
@@ -872,7 +899,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     WSYNC();
     for (int r = 0; r < ne; r++) {
       u64 key = ((u64)uni(fbits(nb_d[r])) << 32) | ((u64)uni(nb_ids[r]) << 1);
-      if constexpr (RB) beam_insert_rb(s, rb, key, 0x7FFFFFFF);
+      if constexpr (RB) beam_insert_rb<RCN>(s, rb, key, 0x7FFFFFFF);
       else beam_insert(s, key, 0x7FFFFFFF);
     }
   }
@@ -888,16 +915,23 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     u64 ta = ~0ull;
     if constexpr (RB) {
       const int len = s.res_len;
-      const bool un0 = ln < len && !(rb.r0 & 1ull), un1 = ln + 64 < len && !(rb.r1 & 1ull);
-      const u64 m0 = __ballot(un0), m1 = __ballot(un1);
-      first_un = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : -1);
-      dmax = (u32)(rb_get(rb, len - 1) >> 32);
+      bool un[RCN];
+#pragma unroll
+      for (int c = RCN - 1; c >= 0; c--) {
+        un[c] = ln + 64 * c < len && !(rb.r[c] & 1ull);
+        const u64 mk = __ballot(un[c]);
+        if (mk) first_un = 64 * c + __ffsll((long long)mk) - 1; // the lowest chunk wins (descending loop)
+      }
+      dmax = (u32)(rb_get<RCN>(rb, len - 1) >> 32);
       last = first_un;
       if (first_un >= 0) { // pop-order key: distance bits ascending, then id DESCENDING
-        const u32 d0 = (u32)(rb_get(rb, first_un) >> 32);
-        const u64 t0 = __ballot(un0 && (u32)(rb.r0 >> 32) == d0), t1 = __ballot(un1 && (u32)(rb.r1 >> 32) == d0);
-        last = t1 ? 127 - __clzll((long long)t1) : 63 - __clzll((long long)t0);
-        ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get(rb, last) & 0xFFFFFFFEull));
+        const u32 d0 = (u32)(rb_get<RCN>(rb, first_un) >> 32);
+#pragma unroll
+        for (int c = 0; c < RCN; c++) {
+          const u64 tk = __ballot(un[c] && (u32)(rb.r[c] >> 32) == d0);
+          if (tk) last = 64 * c + 63 - __clzll((long long)tk); // the highest chunk wins
+        }
+        ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get<RCN>(rb, last) & 0xFFFFFFFEull));
       }
     } else {
     for (int base = 0; base < s.res_len; base += 64) {
@@ -965,9 +999,9 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       if (weird_bits(fb)) s.n_weird--;
       WSYNC();
     } else if constexpr (RB) {
-      cslot = (u32)(rb_get(rb, last) >> 1) & 0x7FFFFFFFu;
-      rb.r0 |= (u64)(ln == last);
-      rb.r1 |= (u64)(ln + 64 == last);
+      cslot = (u32)(rb_get<RCN>(rb, last) >> 1) & 0x7FFFFFFFu;
+#pragma unroll
+      for (int c = 0; c < RCN; c++) rb.r[c] |= (u64)(ln + 64 * c == last);
     } else {
       cslot = uni((u32)(s.res[last] >> 1) & 0x7FFFFFFFu);
       WSYNC();
@@ -1031,7 +1065,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       WSYNC();
       if constexpr (RB) {
         if (__popcll(amask) >= HNY_RB_MERGE_MIN && HNY_RB_MERGE) { // one key: the plain insert is cheaper
-          beam_merge_rb(s, rb, acc, ((u64)fbits(myd) << 32) | ((u64)myid << 1), ef);
+          beam_merge_rb<RCN>(s, rb, acc, ((u64)fbits(myd) << 32) | ((u64)myid << 1), ef);
           amask = 0ull;
         }
       }
@@ -1043,7 +1077,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         amask &= amask - 1ull;
         u32 db = (u32)__builtin_amdgcn_readlane((int)fbits(myd), r);
         u32 idr = (u32)__builtin_amdgcn_readlane((int)myid, r);
-        if constexpr (RB) beam_insert_rb(s, rb, ((u64)db << 32) | ((u64)idr << 1), ef);
+        if constexpr (RB) beam_insert_rb<RCN>(s, rb, ((u64)db << 32) | ((u64)idr << 1), ef);
         else beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
       }
     }
@@ -1060,8 +1094,10 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 5
 #endif
-template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, bool RB = false>
+template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, int RC = 0>
 __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+  constexpr bool RB = RC != 0;
+  constexpr int RCN = RC ? RC : 1;
   static_assert(!(RB && (BIG_EPS || SP == 0)), "register beam: specialised kernels only");
   GraphDev g = g_in;
   WalkArgs a = a_in;
@@ -1086,9 +1122,9 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   s.n_weird = 0;
   s.tie_bits = 0;
   s.dropped = false;
-  BeamR rb;
-  rb.r0 = 0ull;
-  rb.r1 = 0ull;
+  BeamR<RCN> rb;
+#pragma unroll
+  for (int c = 0; c < RCN; c++) rb.r[c] = 0ull;
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u), a.vis_slots);
@@ -1141,11 +1177,11 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH, BIG_EPS, RB>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+      walk_one_layer<LPR, NCH, BIG_EPS, RC>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                    nb_d, evals, err_iter, qrow, rb);
       if (last) break;
       // :305-306 eps = [closest]
-      const u32 closest = RB ? (u32)(rb_get(rb, 0) >> 1) & 0x7FFFFFFFu : uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
+      const u32 closest = RB ? (u32)(rb_get<RCN>(rb, 0) >> 1) & 0x7FFFFFFFu : uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
       if (ln == 0) eps[0] = closest;
       n_eps = 1;
       // locality key: the closest node of the last three greedy layers, coarse to fine
@@ -1168,10 +1204,10 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     }
     // result, ascending (res.into_vec() is re-sorted by robust_prune anyway, :573)
     if constexpr (RB) {
-      if (ln < s.res_len)
-        a.cand[(size_t)m * a.rcap + ln] = (rb.r0 & 0xFFFFFFFF00000000ull) | ((rb.r0 >> 1) & 0x7FFFFFFFull);
-      if (ln + 64 < s.res_len)
-        a.cand[(size_t)m * a.rcap + 64 + ln] = (rb.r1 & 0xFFFFFFFF00000000ull) | ((rb.r1 >> 1) & 0x7FFFFFFFull);
+#pragma unroll
+      for (int c = 0; c < RCN; c++)
+        if (ln + 64 * c < s.res_len)
+          a.cand[(size_t)m * a.rcap + 64 * c + ln] = (rb.r[c] & 0xFFFFFFFF00000000ull) | ((rb.r[c] >> 1) & 0x7FFFFFFFull);
     } else {
       for (int e = ln; e < s.res_len; e += 64) {
         u64 k = s.res[e];
@@ -1208,16 +1244,17 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS, RB>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        walk_one_layer<LPR, NCH, BIG_EPS, RC>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
         }
         if constexpr (RB) { // neighbours.extend(more_nns)
-          if (ln < s.res_len)
-            a.cand[(size_t)m * a.rcap + total + ln] = (rb.r0 & 0xFFFFFFFF00000000ull) | ((rb.r0 >> 1) & 0x7FFFFFFFull);
-          if (ln + 64 < s.res_len)
-            a.cand[(size_t)m * a.rcap + total + 64 + ln] = (rb.r1 & 0xFFFFFFFF00000000ull) | ((rb.r1 >> 1) & 0x7FFFFFFFull);
+#pragma unroll
+          for (int c = 0; c < RCN; c++)
+            if (ln + 64 * c < s.res_len)
+              a.cand[(size_t)m * a.rcap + total + 64 * c + ln] =
+                  (rb.r[c] & 0xFFFFFFFF00000000ull) | ((rb.r[c] >> 1) & 0x7FFFFFFFull);
         } else {
           for (int e = ln; e < s.res_len; e += 64) {
             u64 k = s.res[e];
@@ -1452,7 +1489,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
   s.n_weird = 0;
   s.tie_bits = 0;
   s.dropped = false;
-  BeamR rb_unused{0ull, 0ull};
+  BeamR<1> rb_unused{{0ull}};
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + a.eps_cap, a.vis_slots);
@@ -2540,11 +2577,13 @@ struct Hot {
           const char *e = getenv("HNY_NO_RB"); // read per launch: tests flip it inside one process
           if (a.rcap <= 128 && !(e && atoi(e) != 0)) {
             if (a.reader_mode)
-              hipLaunchKernelGGL((k_walk<L, C, false, SP, true, true>), dim3(grid), dim3(64), lds, st, g, a);
+              hipLaunchKernelGGL((k_walk<L, C, false, SP, true, 2>), dim3(grid), dim3(64), lds, st, g, a);
             else
-              hipLaunchKernelGGL((k_walk<L, C, false, SP, false, true>), dim3(grid), dim3(64), lds, st, g, a);
+              hipLaunchKernelGGL((k_walk<L, C, false, SP, false, 2>), dim3(grid), dim3(64), lds, st, g, a);
             return hipGetLastError();
           }
+          // (a 4-chunk register beam for ef 128..255 was measured and is slower than the LDS beam:
+          // 128-d efC=200 walk 0.85 -> 1.00 s, 768-d (C3) 0.62 -> 0.68 s — registers spill)
         }
         if (a.reader_mode) {
           hipLaunchKernelGGL((k_walk<L, C, false, SP, true>), dim3(grid), dim3(64), lds, st, g, a);
