@@ -276,14 +276,14 @@ def main():
                       f"{cores} threads (rayon-like), AVX2+FMA kernels; a smaller index is cheaper "
                       f"per insert than the 1M one, so this flatters the CPU",
             "seconds": round(tc, 2)}
-        full = os.path.join(ROOT, "profiles", "r01_c2_full_scale_recall_parity.json")
+        full = os.path.join(ROOT, "profiles", "r01_c2_full_scale_recall_parity_final.json")
         if default_c2 and os.path.exists(full):  # one-off measurement of the same baseline at full size
             with open(full) as f:
                 fj = json.load(f)
             out["cpu_baseline"]["full_size_run"] = {
                 "vectors_per_s": round(fj["cpu_vec_per_s"], 1), "seconds": round(fj["cpu_build_s"], 1),
                 "cores": fj["cores"], "recall_at_10": fj["recall_cpu_built_cpu_search"],
-                "source": "profiles/r01_c2_full_scale_recall_parity.json (scripts/recall_parity_full.py)"}
+                "source": "profiles/r01_c2_full_scale_recall_parity_final.json (scripts/recall_parity_full.py)"}
         # recall parity on the sample: CPU-built vs GPU-built graph, both searched by the oracle
         if not a.no_recall and a.queries:
             sub = H.ItemSet(metric, a.dim, ds.ids, ds.codes, ds.headers, lv)
