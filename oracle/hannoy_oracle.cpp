@@ -683,6 +683,22 @@ float orc_distance(int32_t metric, int32_t order, uint32_t dim, const void *pv, 
   Dist d{metric, order, dim, vec_bytes(metric, dim)};
   return d(pv, ph, qv, qh);
 }
+// the same for many pairs of stored items (test helper: >= 1M-pair distance parity)
+void orc_distance_pairs(int32_t metric, int32_t order, uint32_t dim, const void *codes, size_t code_stride,
+                        const void *headers, size_t header_stride, uint64_t n_pairs, const uint32_t *a,
+                        const uint32_t *b, float *out, int32_t threads) {
+  Dist d{metric, order, dim, vec_bytes(metric, dim)};
+  const uint8_t *cv = (const uint8_t *)codes, *hv = (const uint8_t *)headers;
+  unsigned nt = threads > 0 ? (unsigned)threads : 1u;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&, t]() {
+      for (uint64_t i = n_pairs * t / nt; i < n_pairs * (t + 1) / nt; i++)
+        out[i] = d(cv + (size_t)a[i] * code_stride, hv + (size_t)a[i] * header_stride,
+                   cv + (size_t)b[i] * code_stride, hv + (size_t)b[i] * header_stride);
+    });
+  for (auto &x : th) x.join();
+}
 float orc_dot(int32_t order, uint32_t dim, const float *a, const float *b) {
   return order == ORC_ORDER_X86 ? dot_x86(a, b, dim) : wave_reduce(WOP_DOT, a, b, dim);
 }

@@ -87,6 +87,9 @@ void orc_make_header(int32_t metric, uint32_t dim, const void *vec_bytes, void *
 /* ---- distances (src/distance/, all files) ---- */
 float orc_distance(int32_t metric, int32_t order, uint32_t dim, const void *pv, const void *ph,
                    const void *qv, const void *qh);
+void orc_distance_pairs(int32_t metric, int32_t order, uint32_t dim, const void *codes, size_t code_stride,
+                        const void *headers, size_t header_stride, uint64_t n_pairs, const uint32_t *a,
+                        const uint32_t *b, float *out, int32_t threads);
 float orc_dot(int32_t order, uint32_t dim, const float *a, const float *b);
 float orc_sqeuclid(int32_t order, uint32_t dim, const float *a, const float *b);
 /* scalar emulation of the AVX/SSE kernels (always available), for self-checks

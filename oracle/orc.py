@@ -156,6 +156,20 @@ def distance(metric, order, dim, pv, ph, qv, qh):
     return float(lib().orc_distance(metric, order, dim, _p(pv), _p(ph), _p(qv), _p(qh)))
 
 
+def distance_pairs(ds, order, a, b, threads=8):
+    """distance(item a[i], item b[i]) for many pairs of a Dataset's items (indices, not ids)"""
+    a = np.ascontiguousarray(a, np.uint32)
+    b = np.ascontiguousarray(b, np.uint32)
+    out = np.zeros(len(a), np.float32)
+    L = lib()
+    L.orc_distance_pairs.restype = None
+    L.orc_distance_pairs.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.orc_distance_pairs(ds.metric, order, ds.dim, _p(ds.codes), ds.codes.shape[1], _p(ds.headers),
+                         ds.headers.shape[1], len(a), _p(a), _p(b), _p(out), threads)
+    return out
+
+
 def dot(order, a, b):
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)

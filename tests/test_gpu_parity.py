@@ -68,6 +68,43 @@ def test_pair_distances_bit_exact_wave_order(orc, hny, metric, dim):
         assert np.max(np.abs(got - want_x86) / np.maximum(want_x86, 1e-30)) <= 1e-5
 
 
+@pytest.mark.parametrize("metric,dim,data", [(0, 768, "clustered"), (1, 768, "uniform"), (2, 128, "uniform"),
+                                             (3, 1024, "uniform"), (4, 768, "clustered")])
+def test_million_pair_distance_parity(orc, hny, metric, dim, data):
+    """>= 1 M random (query, candidate) pairs per metric class.  The device distances
+    equal the oracle's wave order bit for bit; strict mode (x86_order) equals the reference's AVX2+FMA
+    order bit for bit; the two orders agree within the north-star tolerance (1e-5 relative on squared
+    L2 / L1, 1e-6 absolute on (1-cos)/2, exactly for the integer metrics)."""
+    rng = np.random.default_rng(900 + metric)
+    n, npairs = 20000, 1_000_000
+    if data == "clustered":
+        cent = rng.uniform(-1, 1, (64, dim)).astype(np.float32)
+        vecs = (cent[rng.integers(0, 64, n)] + 0.15 * rng.standard_normal((n, dim))).astype(np.float32)
+    else:
+        vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    lv = np.zeros(n, np.uint8)
+    lv[0] = 1
+    ds, items = _mk(orc, hny, metric, vecs, lv)
+    a = rng.integers(0, n, npairs).astype(np.uint32)
+    c = rng.integers(0, n, npairs).astype(np.uint32)
+    c[:1000] = a[:1000]  # identical operands too
+    with hny.Builder(items, M=4, M0=8) as b:
+        got = b.distances(a, c)
+    want_wave = orc.distance_pairs(ds, orc.ORDER_WAVE, a, c, threads=16)
+    assert np.array_equal(got.view(np.uint32), want_wave.view(np.uint32))
+    want_x86 = orc.distance_pairs(ds, orc.ORDER_X86, a, c, threads=16)
+    if metric >= 3:
+        assert np.array_equal(got.view(np.uint32), want_x86.view(np.uint32))
+    else:
+        with hny.Builder(items, M=4, M0=8, x86_order=True) as b:
+            strict = b.distances(a, c)
+        assert np.array_equal(strict.view(np.uint32), want_x86.view(np.uint32))
+        if metric == 0:
+            assert np.max(np.abs(got - want_x86)) <= 1e-6
+        else:
+            assert np.max(np.abs(got - want_x86) / np.maximum(want_x86, 1e-30)) <= 1e-5
+
+
 CASES = [
     # metric, n, dim, M, M0, ef, frac, bmax
     (1, 200, 16, 3, 3, 20, 0.0, 1),
