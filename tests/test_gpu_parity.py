@@ -1,4 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, same seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -225,7 +227,8 @@ def test_kat2_3_4_incremental_on_gpu(kat, orc, hny):
 @pytest.mark.parametrize("metric,dim,M,M0,ef,frac,bmax", [(1, 24, 6, 12, 32, 0.0, 1), (0, 48, 8, 16, 40, 0.1, 64),
                                                            (3, 128, 8, 16, 24, 0.1, 32)])
 def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac, bmax):
-    """Two rounds of random deletes / overwrites / additions: GPU == oracle edge for edge."""
+    """Rounds of random deletes / overwrites / additions (2; HNY_TEST_INCR_ROUNDS for a longer soak):
+    GPU == oracle edge for edge."""
     rng = np.random.default_rng(dim + M)
     n0 = 1500
     vecs = {i: rng.uniform(-1, 1, dim).astype(np.float32) for i in range(n0)}
@@ -243,7 +246,7 @@ def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac,
     gg = hny.build(items, **kw_g)
     _same_graph(gg, og)
     next_id = n0
-    for rnd in range(2):
+    for rnd in range(int(os.environ.get("HNY_TEST_INCR_ROUNDS", "2"))):
         alive = sorted(vecs.keys())
         to_delete = sorted(rng.choice(alive, 120, replace=False).tolist())
         for i in to_delete:
