@@ -295,15 +295,28 @@ class Writer:
         if meta is None:
             raise MissingMetadata("The metadata must be there")
         keep = set(meta["items"].tolist())
+        snapshot = dict(self.db.kv)  # the reference works inside one RwTxn that is aborted on error
         llo, lhi = key(self.index, MODE_LINKS), key(self.index, MODE_LINKS, 0xFFFFFFFF, 0xFF)
         for k in [k for k in self.db.kv if llo <= k <= lhi]:  # delete_links_from_db(&item_ids)
             if struct.unpack(">HBIB", k)[2] in keep:
                 del self.db.kv[k]
-        return self.build(levels=levels, relink_all_items=True, **opts)
+        try:
+            return self.build(levels=levels, relink_all_items=True, **opts)
+        except BaseException:
+            self.db.kv = snapshot
+            raise
 
     def build(self, levels=None, relink_all_items=False, rng=None, **opts):
         """Writer::build (writer.rs:521-603).  `levels`: optional {item id: level} for the items that
         get (re)inserted, instead of drawing them from StdRng::seed_from_u64(self.seed)."""
+        snapshot = dict(self.db.kv)  # writer.rs:521-603 runs in the caller's RwTxn: an error (cancel,
+        try:                         # unsupported, device, OOM) aborts it and nothing is changed
+            return self._build(levels, relink_all_items, rng, opts)
+        except BaseException:
+            self.db.kv = snapshot
+            raise
+
+    def _build(self, levels, relink_all_items, rng, opts):
         db, index = self.db, self.index
         meta = db.metadata(index)
         indexed = set(meta["items"].tolist()) if meta else set()

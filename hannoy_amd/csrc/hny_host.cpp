@@ -1304,6 +1304,13 @@ int hny_builder_sync(hny_builder *b) {
   return HNY_OK;
 }
 
+// the device error words are reported once, then cleared (they sit behind the counters in d_stats)
+static hipError_t clear_error_counters(hny_builder *b) {
+  static_assert(ST_ERR_GAPS_OVERFLOW == ST_ERR_RES_OVERFLOW + 2 && ST_ERR_ITER == ST_ERR_RES_OVERFLOW + 1,
+                "error words are contiguous");
+  return hipMemsetAsync(b->d_stats.p + ST_ERR_RES_OVERFLOW, 0, 3 * sizeof(u64), b->stream);
+}
+
 void hny_graph_free(hny_graph *g) {
   if (!g) return;
   free((void *)g->rec_item);
@@ -1326,9 +1333,11 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   const uint32_t n = b->n, M = b->o.M, M0 = b->o.M0, ml = b->max_level;
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER] || stats[ST_ERR_GAPS_OVERFLOW])
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER] || stats[ST_ERR_GAPS_OVERFLOW]) {
+    (void)clear_error_counters(b); // reported once: a later reset / search starts clean
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu gaps=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW]);
+  }
   // finalise every list on the device (sort + dedup), then copy through pinned staging
   const uint32_t upl = b->up_layers;
   const size_t nup = (size_t)b->n_upper * upl;
@@ -1361,10 +1370,21 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   std::vector<uint64_t> rec_first(n + 1, 0);
   for (uint32_t s = 0; s < n; s++) rec_first[s + 1] = rec_first[s] + (uint32_t)__builtin_popcount(rec_mask(s));
   const uint64_t nrec = rec_first[n];
-  hny_graph *g = (hny_graph *)calloc(1, sizeof(hny_graph));
+  // the graph owns its arrays from the start, so that every error return below frees them
+  std::unique_ptr<hny_graph, void (*)(hny_graph *)> gh((hny_graph *)calloc(1, sizeof(hny_graph)), hny_graph_free);
+  hny_graph *g = gh.get();
   uint32_t *rec_item = (uint32_t *)malloc(std::max<uint64_t>(nrec, 1) * 4);
   uint8_t *rec_layer = (uint8_t *)malloc(std::max<uint64_t>(nrec, 1));
   uint64_t *rec_off = (uint64_t *)malloc((nrec + 1) * 8);
+  if (!g || !rec_item || !rec_layer || !rec_off) {
+    free(rec_item);
+    free(rec_layer);
+    free(rec_off);
+    return fail(HNY_ERR_OOM, "out of host memory for %llu records", (unsigned long long)nrec);
+  }
+  g->rec_item = rec_item;
+  g->rec_layer = rec_layer;
+  g->rec_offset = rec_off;
   rec_off[0] = 0;
   HIP_TRY(hipEventSynchronize(ev_counts));
   for (uint32_t s = 0; s < n; s++) { // offsets: sequential prefix over the device-computed counts
@@ -1377,6 +1397,8 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
     }
   }
   uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
+  if (!nbrs) return fail(HNY_ERR_OOM, "out of host memory for %llu links", (unsigned long long)rec_off[nrec]);
+  g->neighbours = nbrs;
   HIP_TRY(hipStreamSynchronize(b->stream)); // the lists have arrived
   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (n < 10000) nt = 1;
@@ -1405,10 +1427,6 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   uint32_t *eps = (uint32_t *)malloc(std::max<size_t>(b->entry_points.size(), 1) * 4);
   for (size_t i = 0; i < b->entry_points.size(); i++) eps[i] = b->ids[b->entry_points[i]];
   g->n_records = nrec;
-  g->rec_item = rec_item;
-  g->rec_layer = rec_layer;
-  g->rec_offset = rec_off;
-  g->neighbours = nbrs;
   g->entry_points = eps;
   g->n_entry_points = (uint32_t)b->entry_points.size();
   g->max_level = ml;
@@ -1442,7 +1460,7 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
     (void)cnt;
     g->n_walk_launches = b->n_walk_dispatch; // k_walk dispatches (rocprofv3 counts the same)
   }
-  *out = g;
+  *out = gh.release();
   return HNY_OK;
 }
 
@@ -1452,16 +1470,12 @@ int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **ou
   hny_builder *b = nullptr;
   int rc = hny_builder_create(opts, items, &b);
   if (rc) return rc;
-  uint64_t since_probe = 0;
   for (;;) {
-    // cancel: probed between batches, i.e. at least every CANCELLATION_PROBING items as long as
-    // batch_max <= 10 000 ... 16 384 (lib.rs:140, hnsw.rs:174-177)
-    if (opts->cancel && (since_probe == 0 || since_probe >= 10000)) {
-      since_probe = 0;
-      if (opts->cancel(opts->cancel_ctx)) {
-        hny_builder_destroy(b);
-        return fail(HNY_ERR_CANCELLED, "build cancelled");
-      }
+    // cancel: probed before every batch, i.e. every <= batch_max items (the reference probes every
+    // CANCELLATION_PROBING = 10 000 items, lib.rs:140, hnsw.rs:174-177)
+    if (opts->cancel && opts->cancel(opts->cancel_ctx)) {
+      hny_builder_destroy(b);
+      return fail(HNY_ERR_CANCELLED, "build cancelled");
     }
     hny_batch bt;
     rc = hny_builder_next_batch(b, &bt);
@@ -1470,7 +1484,6 @@ int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **ou
     if (rc) break;
     rc = hny_builder_apply(b, nullptr);
     if (rc) break;
-    since_probe += bt.count;
     if (opts->progress) opts->progress(opts->progress_ctx, b->pos, b->order.size());
   }
   if (!rc) rc = hny_builder_finish(b, out);
@@ -1521,14 +1534,10 @@ int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, co
   hny_builder *b = nullptr;
   int rc = create_impl(opts, items, &inc, &b);
   if (rc) return rc;
-  uint64_t since_probe = 0;
   for (;;) {
-    if (opts->cancel && (since_probe == 0 || since_probe >= 10000)) {
-      since_probe = 0;
-      if (opts->cancel(opts->cancel_ctx)) {
-        hny_builder_destroy(b);
-        return fail(HNY_ERR_CANCELLED, "build cancelled");
-      }
+    if (opts->cancel && opts->cancel(opts->cancel_ctx)) {
+      hny_builder_destroy(b);
+      return fail(HNY_ERR_CANCELLED, "build cancelled");
     }
     hny_batch bt;
     rc = hny_builder_next_batch(b, &bt);
@@ -1537,7 +1546,6 @@ int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, co
     if (rc) break;
     rc = hny_builder_apply(b, nullptr);
     if (rc) break;
-    since_probe += bt.count;
     if (opts->progress) opts->progress(opts->progress_ctx, b->pos, b->order.size());
   }
   if (!rc) rc = run_fill_gaps(b);
@@ -1676,9 +1684,11 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
   }
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER]) {
+    (void)clear_error_counters(b); // not sticky: the next search on this builder starts clean
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER]);
+  }
   return HNY_OK;
 }
 
@@ -1882,9 +1892,11 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
   }
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER])
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER]) {
+    (void)clear_error_counters(b); // not sticky: the next search on this builder starts clean
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER]);
+  }
   return HNY_OK;
 }
 
@@ -1957,6 +1969,7 @@ static const char *metric_name(int m) {
 int hny_encode_kv(const hny_graph *g, const hny_build_opts *opts, const hny_items *items,
                   uint16_t index, int with_items, hny_kv_sink sink, void *ctx) {
   if (!g || !opts || !items || !sink) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  if (opts->metric < 0 || opts->metric > HNY_BQ_MANHATTAN) return fail(HNY_ERR_INVALID_ARG, "bad metric");
   uint8_t key[8];
   std::vector<uint8_t> val;
   auto emit = [&]() { return sink(ctx, key, 8, val.data(), val.size()); };

@@ -2271,17 +2271,24 @@ __global__ __launch_bounds__(64) void k_apply_merge(GraphDev g, const u64 *exch,
 //   bm = (old links  U  old links of every DELETED old neighbour)  -  deleted       (:382-388)
 //   |bm| + |new| <= cap :  list = [(0.0, j) for j in bm ascending] ++ new           (:391-400)
 //   else               :  list = robust_prune(new ++ [(d(slot, j), j) for j in bm]) (:403-410)
-#define HNY_GAPS_MAXU 1024
+// Scratch: own old links + the old links of every deleted old neighbour = at most cap * (cap + 1)
+// ids (1 056 at M0 = 32, 4 160 at M0 = 64) — a mass deletion reaches that — so the LDS arrays are
+// sized for the worst case by the launcher (`maxu`), never for a typical one.
+__host__ __device__ inline size_t fill_gaps_lds_bytes(u32 maxu) {
+  return (size_t)maxu * 4 * 2 + (size_t)(maxu + HNY_MAX_CAP) * 8 * 2 + HNY_MAX_CAP * (8 + 4) + 64 * 4;
+}
 template <int LPR, int NCH>
 __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u32 n_recs,
-                                                  const unsigned char *deleted) {
-  __shared__ u32 cand[HNY_GAPS_MAXU];
-  __shared__ u32 bm[HNY_GAPS_MAXU];
-  __shared__ u64 keys[HNY_GAPS_MAXU + HNY_MAX_CAP];
-  __shared__ u64 sorted[HNY_GAPS_MAXU + HNY_MAX_CAP];
-  __shared__ u64 S[HNY_MAX_CAP];
-  __shared__ u32 s_ids[HNY_MAX_CAP];
-  __shared__ float tmp_d[64];
+                                                  const unsigned char *deleted, u32 maxu) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *keys = reinterpret_cast<u64 *>(smem);            // [maxu + HNY_MAX_CAP]
+  u64 *sorted = keys + (maxu + HNY_MAX_CAP);            // [maxu + HNY_MAX_CAP]
+  u64 *S = sorted + (maxu + HNY_MAX_CAP);               // [HNY_MAX_CAP]
+  u32 *cand = reinterpret_cast<u32 *>(S + HNY_MAX_CAP); // [maxu]
+  u32 *bm = cand + maxu;                                // [maxu]
+  u32 *s_ids = bm + maxu;                               // [HNY_MAX_CAP]
+  float *tmp_d = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP); // [64]
+  const int MAXU = (int)maxu;
   const int ln = threadIdx.x, t = ln % LPR;
   u64 evals = 0;
   u32 overflow = 0;
@@ -2309,7 +2316,7 @@ __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u
     for (u32 j = 0; j < dcap; j++) {
       const u32 x = uni(dl[j]);
       if (x == HNY_SENT) break;
-      if (nu < HNY_GAPS_MAXU && ln == 0) cand[nu] = x;
+      if (nu < MAXU && ln == 0) cand[nu] = x;
       nu++;
       if (deleted[x]) {
         u32 c2;
@@ -2319,12 +2326,12 @@ __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u
           const bool v = y != HNY_SENT;
           const u64 m = __ballot(v);
           const int pos = nu + __popcll(m & ((1ull << ln) - 1ull));
-          if (v && pos < HNY_GAPS_MAXU) cand[pos] = y;
+          if (v && pos < MAXU) cand[pos] = y;
           nu += __popcll(m);
         }
       }
     }
-    if (nu > HNY_GAPS_MAXU) {
+    if (nu > MAXU) { // cannot happen: maxu is the worst case (old lists hold <= cap ids)
       overflow++;
       continue;
     }
@@ -2661,7 +2668,15 @@ struct GapsLauncher {
   static hipError_t run(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
                         hipStream_t st) {
     int grid = n_recs < 16384u ? (int)n_recs : 16384;
-    hipLaunchKernelGGL((k_fill_gaps<L, C>), dim3(grid), dim3(64), 0, st, g, recs, n_recs, deleted);
+    const u32 cap = g.M0 > g.M ? g.M0 : g.M;
+    const u32 maxu = cap * (cap + 1u);
+    const size_t lds = fill_gaps_lds_bytes(maxu);
+    if (lds > 65536) {
+      hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_gaps<L, C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (rc != hipSuccess) return rc;
+    }
+    hipLaunchKernelGGL((k_fill_gaps<L, C>), dim3(grid), dim3(64), lds, st, g, recs, n_recs, deleted, maxu);
     return hipGetLastError();
   }
 };

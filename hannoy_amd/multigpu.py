@@ -86,6 +86,8 @@ class Driver:
             b.sync()
             self._all_gather(ex, per2 * xs)
             b.apply_merge(ex.data_ptr(), self.rank, self.world)
+        if getattr(b, "incremental", False):  # fill_gaps_from_deleted (hnsw.rs:187): deterministic,
+            b.fill_gaps()                     # computed by every replica like Builder.run() does
         return n
 
     def _all_gather(self, full, words_per_rank):

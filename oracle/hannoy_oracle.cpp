@@ -444,6 +444,7 @@ struct Scratch {
   std::vector<uint32_t> stamp;
   uint32_t epoch = 0;
   uint64_t evals = 0;
+  uint64_t evals_walk = 0; /* the hnsw.rs:476,503 call sites alone (schedule-determined) */
   std::vector<uint32_t> nbuf;
   void begin(uint32_t n) {
     if (stamp.size() != n) {
@@ -488,6 +489,7 @@ void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint3
   };
   for (uint32_t ep : eps) { /* :474-481 — no capacity check on res here */
     Link l{qd(ep, S.evals), ep};
+    S.evals_walk++;
     cand.push(l);
     res_insert(l);
     S.visit(ep);
@@ -513,6 +515,7 @@ void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint3
       if (!S.visit(p)) continue; /* :493 */
       if (B.incremental && !B.has_vec[p]) continue; /* MissingKey => deleted item, :498-502 */
       float d = qd(p, S.evals);  /* :503 */
+      S.evals_walk++;
       if (res.size() < ef || d < f_max) { /* :505, f_max captured once per pop */
         Link l{d, p};
         cand.push(l);
@@ -616,7 +619,7 @@ struct orc_graph {
   std::vector<float> raw_dists;
   std::vector<uint32_t> entry_points; /* item ids */
   uint32_t max_level = 0;
-  uint64_t n_evals = 0, n_links = 0;
+  uint64_t n_evals = 0, n_links = 0, n_evals_walk = 0;
 };
 
 extern "C" {
@@ -968,7 +971,11 @@ int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
     for (uint32_t i = 0; i < n; i++) ord[i] = {order[i], B.level[order[i]]};
     run_schedule(B, opts, ord, 0, scratch, evals, links);
   }
-  for (auto &s : scratch) evals += s.evals;
+  uint64_t evals_walk = 0;
+  for (auto &s : scratch) {
+    evals += s.evals;
+    evals_walk += s.evals_walk;
+  }
 
   /* hnsw.rs:191-213 write loop, emitted sorted by (item, layer) = LMDB key order (key.rs:54-66) */
   g->max_level = B.max_level;
@@ -995,6 +1002,7 @@ int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
       g->offsets.push_back(g->nbrs.size());
     }
   g->n_evals = evals;
+  g->n_evals_walk = evals_walk;
   g->n_links = links;
   *out = g.release();
   return 0;
@@ -1132,7 +1140,10 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
   B.threaded = false;
   Scratch &S = scratch[0];
   S.evals += evals;
-  for (int t = 1; t < nthreads; t++) S.evals += scratch[t].evals;
+  for (int t = 1; t < nthreads; t++) {
+    S.evals += scratch[t].evals;
+    S.evals_walk += scratch[t].evals_walk;
+  }
 
   /* fill_gaps_from_deleted, hnsw.rs:334-415 */
   {
@@ -1205,6 +1216,7 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
       g->offsets.push_back(g->nbrs.size());
     }
   g->n_evals = S.evals;
+  g->n_evals_walk = S.evals_walk;
   g->n_links = links;
   *out = g.release();
   return 0;
@@ -1234,6 +1246,7 @@ uint32_t orc_graph_entry_points(const orc_graph *g, uint32_t *out, uint32_t cap)
 }
 uint32_t orc_graph_max_level(const orc_graph *g) { return g->max_level; }
 uint64_t orc_graph_distance_evals(const orc_graph *g) { return g->n_evals; }
+uint64_t orc_graph_walk_evals(const orc_graph *g) { return g->n_evals_walk; }
 uint64_t orc_graph_links_added(const orc_graph *g) { return g->n_links; }
 
 /* ------------------------------------------------------------------ */

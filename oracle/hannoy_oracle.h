@@ -141,6 +141,9 @@ void orc_graph_export_raw(const orc_graph *g, uint64_t *offsets, uint32_t *nbrs,
 uint32_t orc_graph_entry_points(const orc_graph *g, uint32_t *out, uint32_t cap);
 uint32_t orc_graph_max_level(const orc_graph *g);
 uint64_t orc_graph_distance_evals(const orc_graph *g);
+/* distance evaluations inside walk_layer alone (hnsw.rs:476, 503): determined by the schedule, so the
+ * GPU build must report the same number (it is the numerator of bench.py's roofline) */
+uint64_t orc_graph_walk_evals(const orc_graph *g);
 uint64_t orc_graph_links_added(const orc_graph *g);
 
 /* QueryBuilder options beyond count / ef_search (reader.rs:60-67, 200-262) */

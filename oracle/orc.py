@@ -85,7 +85,7 @@ def lib():
                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.POINTER(PrevGraph), C.POINTER(C.c_void_p)]
         for name in ("orc_graph_n_records", "orc_graph_n_links", "orc_graph_n_raw",
-                     "orc_graph_distance_evals", "orc_graph_links_added"):
+                     "orc_graph_distance_evals", "orc_graph_links_added", "orc_graph_walk_evals"):
             getattr(L, name).restype = C.c_uint64
             getattr(L, name).argtypes = [C.c_void_p]
         L.orc_graph_export.argtypes = [C.c_void_p] * 5
@@ -262,6 +262,7 @@ class Graph:
         self.max_level = L.orc_graph_max_level(handle)
         self.n_distance_evals = L.orc_graph_distance_evals(handle)
         self.n_links_added = L.orc_graph_links_added(handle)
+        self.n_evals_walk = L.orc_graph_walk_evals(handle)
 
     def __del__(self):
         try:

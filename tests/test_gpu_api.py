@@ -405,9 +405,18 @@ def test_build_cancel_and_progress(H):
     db = H.Database(None, H.Metric.EUCLIDEAN)
     w = db.writer(8)
     w.add_items(range(500), np.random.default_rng(3).random((500, 8), dtype=np.float32))
+    before = db.dump() if hasattr(db, "dump") else sorted(db.kv.items())
     with pytest.raises(H.BuildCancelled):
         w.builder().cancel(lambda: True).build()
-    w.add_item(0, np.zeros(8, np.float32))  # the cancelled build consumed the `updated` stones
+    # the reference's build runs in the caller's RwTxn, which the error aborts: nothing changed, the
+    # `updated` stones are still there and the next build picks them up
+    assert w.need_build()
+    assert (db.dump() if hasattr(db, "dump") else sorted(db.kv.items())) == before
+    w.builder().build()
+    assert not w.need_build()
+    r = db.reader(0)
+    r.assert_validity()
+    r.close()
     seen = []
     db = H.Database(None, H.Metric.EUCLIDEAN)
     w = db.writer(8)

@@ -71,7 +71,8 @@ def test_pair_distances_bit_exact_wave_order(orc, hny, metric, dim):
 
 
 @pytest.mark.parametrize("metric,dim,data", [(0, 768, "clustered"), (1, 768, "uniform"), (2, 128, "uniform"),
-                                             (3, 1024, "uniform"), (4, 768, "clustered")])
+                                             (3, 1024, "uniform"), (4, 768, "clustered"), (5, 1000, "uniform"),
+                                             (6, 333, "clustered"), (0, 3, "uniform")])
 def test_million_pair_distance_parity(orc, hny, metric, dim, data):
     """>= 1 M random (query, candidate) pairs per metric class.  The device distances
     equal the oracle's wave order bit for bit; strict mode (x86_order) equals the reference's AVX2+FMA
@@ -139,6 +140,71 @@ def test_build_equals_oracle_bit_exact(orc, hny, metric, n, dim, M, M0, ef, frac
     assert g.n_tie_pool_overflow == 0
     _same_graph(g, o)
     assert g.n_links_added == o.n_links_added
+    # walk evaluations are determined by the schedule (hnsw.rs:476, 503 call sites): the numerator of
+    # bench.py's roofline is therefore a checked count.  (Prune / apply counts legitimately differ:
+    # the workgroup prune tests 4 rows per pass and 4 candidates concurrently.)
+    assert g.n_evals_walk == o.n_evals_walk
+
+
+README_3D = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]  # the README example's items (/root/reference/README.md:45-46)
+
+
+def _c1_vectors():
+    """BASELINE config C1: 10 000 x 3 f32, U(-1, 1) (generator shape of src/tests/mod.rs:133-136),
+    with the README example's 3-d vectors in front and a few exact duplicates / a zero vector, which
+    3-d cosine turns into ubiquitous ties, clamp hits and zero distances."""
+    rng = np.random.default_rng(42)
+    v = rng.uniform(-1, 1, (10_000, 3)).astype(np.float32)
+    v[:2] = np.array(README_3D, np.float32)
+    v[2] = [0.0, 0.0, 1.0]
+    v[3] = 0.0                      # zero vector: distance 0 to everything (cosine.rs:47-55)
+    v[4] = v[0] * 2.0               # same direction as item 0: cos = 1 -> clamp
+    v[5] = -v[1]                    # opposite direction: cos = -1 -> distance 1
+    v[100:110] = v[200:210]         # exact duplicates
+    return v
+
+
+def test_c1_readme_config_equals_oracle(orc, hny):
+    """C1 (10k x 3-d Cosine, M=16/M0=32, efC=100), default schedule: GPU == oracle edge for edge in
+    the wave order, with the same number of walk evaluations.  dim < 16 is the reference's scalar
+    summation path (src/spaces/simple.rs:19-47)."""
+    v = _c1_vectors()
+    levels = draw_levels(len(v), 16, seed=42)
+    ds, items = _mk(orc, hny, 0, v, levels)
+    for frac, bmax in ((0.0, 0), (0.05, 256)):
+        kw = dict(batch_frac=frac or 1.0, batch_max=bmax or 65536)
+        o = orc.build(ds, M=16, M0=32, ef=100, order=orc.ORDER_WAVE, threads=8, **kw)
+        g = hny.build(items, M=16, M0=32, ef_construction=100, batch_frac=frac, batch_max=bmax)
+        assert g.n_tie_pool_overflow == 0
+        _same_graph(g, o)
+        assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+
+
+def test_c1_strict_sequential_equals_x86_oracle(orc, hny):
+    """C1 in strict mode with batch_max = 1: the GPU graph equals the oracle's restatement of the
+    reference run with ONE thread and its own x86 (here: scalar, dim < 16) summation order — the
+    mode the reference's snapshot tests pin."""
+    v = _c1_vectors()[:4000]
+    levels = draw_levels(len(v), 16, seed=43)
+    ds, items = _mk(orc, hny, 0, v, levels)
+    o = orc.build(ds, M=16, M0=32, ef=100, order=orc.ORDER_X86)  # batch_max 0 = the reference's loop
+    g = hny.build(items, M=16, M0=32, ef_construction=100, batch_max=1, x86_order=True)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+    # and the README program itself (README.md:43-62): two items, levels drawn from
+    # StdRng::seed_from_u64(42), build::<16,32> with ef_construction 100, then nns(1).ef_search(10)
+    # by the vector [0, 1, 0] -> item 1 at distance 0
+    v2 = np.array(README_3D, np.float32)
+    lv = hny.draw_levels(42, 16, 2)
+    ds2, it2 = _mk(orc, hny, 0, v2, lv)
+    o2 = orc.build(ds2, M=16, M0=32, ef=100, order=orc.ORDER_X86)
+    with hny.Builder(it2, M=16, M0=32, ef_construction=100, batch_max=1, x86_order=True) as b:
+        b.run()
+        g2 = b.finish()
+        qc, qh = hny.encode_vectors(hny.COSINE, np.array([[0.0, 1.0, 0.0]], np.float32))
+        ids, dists, cnt = b.search_knn(qc, qh, k=1, ef_search=10)
+    _same_graph(g2, o2)
+    assert cnt.tolist() == [1] and ids[0, 0] == 1 and dists[0, 0] == 0.0
 
 
 @pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 3000, 96, 8, 16, 48), (1, 2000, 40, 6, 12, 32),
@@ -271,6 +337,37 @@ def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac,
         alive_set = set(vecs.keys())
         assert all(set(nb) <= alive_set for nb in d.values())
         assert {i for (i, l) in d if l == 0} == alive_set
+
+
+@pytest.mark.parametrize("M,M0,keep_frac", [(16, 32, 0.05), (24, 48, 0.04), (32, 64, 0.5)])
+def test_mass_deletion_fill_gaps_worst_case(orc, hny, M, M0, keep_frac):
+    """fill_gaps_from_deleted (hnsw.rs:334-415) when most of the index is removed in one update: a
+    surviving record then gathers its own old links plus the old links of nearly every old
+    neighbour — up to cap * (cap + 1) ids (1 056 at M0 = 32, 2 352 at 48), beyond the 1 024 a
+    fixed scratch held in round 1.  GPU == oracle edge for edge, and the reference's invariants hold
+    (no link to a deleted item, every survivor owns a layer-0 record)."""
+    rng = np.random.default_rng(M0)
+    n, dim = 4000, 16
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    kw_o = dict(M=M, M0=M0, ef=96, order=orc.ORDER_WAVE, batch_frac=0.25, batch_max=256)
+    kw_g = dict(M=M, M0=M0, ef_construction=96, batch_frac=0.25, batch_max=256)
+    ds, items = _mk(orc, hny, 1, vecs, draw_levels(n, M, seed=2))
+    og = orc.build(ds, threads=8, **kw_o)
+    gg = hny.build(items, **kw_g)
+    _same_graph(gg, og)
+    deg0 = np.diff(gg.offsets.astype(np.int64))[gg.rec_layer == 0]
+    assert deg0.max() == M0  # full-degree lists exist
+    keep = np.sort(rng.choice(n, int(n * keep_frac), replace=False)).astype(np.uint32)
+    to_delete = np.setdiff1d(np.arange(n, dtype=np.uint32), keep)
+    ds2 = orc.Dataset.from_f32(1, vecs[keep], np.zeros(len(keep), np.uint8), keep)
+    items2 = hny.ItemSet(1, dim, ds2.ids, ds2.codes, ds2.headers, np.zeros(0, np.uint8))
+    og2 = orc.build_incremental(ds2, og, [], np.zeros(0, np.uint8), to_delete, **kw_o)
+    gg2 = hny.build_incremental(items2, gg, [], to_delete, **kw_g)
+    _same_graph(gg2, og2)
+    d = gg2.as_dict()
+    alive = set(keep.tolist())
+    assert all(set(nb) <= alive for nb in d.values())
+    assert {i for (i, l) in d if l == 0} == alive
 
 
 def test_visited_log_overflow_fallback(orc, hny, monkeypatch):

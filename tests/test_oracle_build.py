@@ -97,3 +97,40 @@ def test_empty_and_single(orc):
                      np.zeros((0, 4), np.uint8), np.zeros(0, np.uint8))
     g = orc.build(ds)
     assert len(g.rec_item) == 0 and len(g.entry_points) == 0
+
+
+def test_c1_readme_config_on_the_oracle(orc):
+    """BASELINE config C1 (10k x 3-d Cosine, M=16/M0=32, efC=100 — the README example's shape,
+    README.md:43-51, generator src/tests/mod.rs:133-136) through the CPU oracle: sequential reference
+    semantics vs the GPU's batch schedule.  dim < 16 takes the reference's scalar summation path
+    (simple.rs:19-47), where x86 and wave order coincide for 3 elements up to fma contraction; both
+    builds are valid and reach the same recall@10 (+-0.5 %)."""
+    rng = np.random.default_rng(42)
+    n, nq = 10_000, 200
+    v = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    v[:2] = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]  # README.md:45-46
+    ds = orc.Dataset.from_f32(orc.COSINE, v, draw_levels(n, 16, 42))
+    seq = orc.build(ds, M=16, M0=32, ef=100, order=orc.ORDER_X86, threads=1)
+    bat = orc.build(ds, M=16, M0=32, ef=100, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=65536, threads=8)
+    _validity(seq, ds)
+    _validity(bat, ds)
+    assert seq.n_evals_walk > 0 and bat.n_evals_walk > 0
+    qs = rng.uniform(-1, 1, (nq, 3)).astype(np.float32)
+    qc = orc.encode_vectors(orc.COSINE, qs)
+    qh = orc.make_headers(orc.COSINE, 3, qc)
+    vn = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)
+    qn = qs / np.linalg.norm(qs, axis=1, keepdims=True)
+    sim = qn.astype(np.float64) @ vn.astype(np.float64).T
+    kth = np.sort(sim, axis=1)[:, -10]
+
+    def recall(g):  # ties are ubiquitous in 3-d: count a hit when the similarity reaches the 10th best
+        ids, _, cnt = orc.search(ds, g, qc, qh, k=10, ef_search=100)
+        hit = sum(int(np.sum(sim[i, ids[i, :cnt[i]]] >= kth[i] - 1e-9)) for i in range(nq))
+        return hit / (10 * nq)
+    r_seq, r_bat = recall(seq), recall(bat)
+    assert r_seq > 0.95 and abs(r_seq - r_bat) <= 0.005
+    # README.md:56-57: nns(1).ef_search(10) by [0, 1, 0] returns item 1 at distance 0
+    q1 = np.array([[0.0, 1.0, 0.0]], np.float32)
+    c1 = orc.encode_vectors(orc.COSINE, q1)
+    ids, dists, cnt = orc.search(ds, seq, c1, orc.make_headers(orc.COSINE, 3, c1), k=1, ef_search=10)
+    assert cnt[0] == 1 and dists[0, 0] == 0.0
