@@ -228,7 +228,8 @@ def main():
                   "t_prune_kernels_s": round(graph.t_prune_kernels_s, 3),
                   "t_sort_kernels_s": round(graph.t_sort_kernels_s, 3),
                   "t_apply_kernels_s": round(graph.t_apply_kernels_s, 3),
-                  "tie_pool_overflow": int(graph.n_tie_pool_overflow)},
+                  "tie_pool_overflow": int(graph.n_tie_pool_overflow),
+                  "sub_wave_walks": int(graph.n_sub_walks), "sub_wave_handed_over": int(graph.n_sub_retries)},
     }
 
     if rank == 0 and not a.no_recall and a.queries:

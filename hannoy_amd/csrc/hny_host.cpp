@@ -264,6 +264,11 @@ struct hny_builder {
   DevBuf<unsigned char> d_has_vec, d_deleted;
   DevBuf<u64> d_old_recs, d_lkey_a, d_lkey_b, d_perm_a, d_perm_b;
   DevBuf<u32> d_eps0;
+  // k_walk_sub (four queries per wave): per-query visited hash tables, the retry list and the work /
+  // retry counters of a search call (3 words per walk launch)
+  DevBuf<u32> d_vtab, d_ctr;
+  DevBuf<u64> d_retry;
+  uint32_t sub_blocks = 0, vtab_slots = 0, ctr_used = 0;
   bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
   DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
@@ -863,6 +868,36 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_perm_a.alloc(cand_rows));
   HIP_TRY(b->d_perm_b.alloc(cand_rows));
   HIP_TRY(b->d_eps0.alloc(cand_rows));
+  {
+    // sub-wave walk: one visited hash table per resident QUERY (4 per wave).  A walk marks about
+    // 0.4 ... 0.6 x ef x M0 items (measured: C5 1 245, C4 1 390); the table wants a load factor
+    // around 1/3 (16-id buckets then almost never fill) and must stay cache resident: 16 KB x
+    // 4 x blocks.  A walk that fills 3/4 of it goes to the one-wave kernel instead.
+    WalkArgs probe{};
+    probe.ef = o.ef_construction;
+    probe.n_entry_points = (u32)b->entry_points.size();
+    probe.cap_sel = o.M0;
+    GraphDev gp{};
+    gp.metric = o.metric;
+    gp.M = o.M;
+    gp.M0 = o.M0;
+    gp.incremental = inc ? 1 : 0;
+    gp.x86_order = o.x86_order ? 1 : 0;
+    if (hnyk_walk_sub_rc(gp, probe, b->shape)) { // HNY_SUB=1 at builder creation
+      uint32_t vs = 512;
+      const uint32_t want = (uint32_t)std::min<int64_t>(
+          std::max(512, env_int("HNY_SUB_VSLOTS", (int)std::min<uint32_t>(4096, o.ef_construction * o.M0 * 3 / 2))),
+          1 << 16);
+      while (vs < want) vs *= 2;
+      b->vtab_slots = vs;
+      b->sub_blocks = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_SUB_BLOCKS", 4096)),
+                                                  (std::max<uint32_t>(b->max_batch, 256) + 3) / 4);
+      HIP_TRY(b->d_vtab.alloc((size_t)b->sub_blocks * 4 * vs));
+      HIP_TRY(hnyk_fill_u32(b->d_vtab.p, HNY_SENT, b->d_vtab.n, st));
+      HIP_TRY(b->d_retry.alloc(cand_rows));
+    }
+    HIP_TRY(b->d_ctr.alloc(3 * 32));
+  }
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(b->d_deferred_b.alloc(b->max_ops));
   {
@@ -1078,6 +1113,34 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   };
   u32 *queues = b->d_nseg.p + 4; // 16 work counters: the descent + one per layer of the batch
   HIP_TRY(hipMemsetAsync(queues, 0, 16 * 4, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_ctr.p, 0, b->d_ctr.n * 4, b->stream));
+  b->ctr_used = 0;
+  // one walk launch: rows <= 512 B go to the four-queries-per-wave kernel first, and the one-wave
+  // kernel then takes the members it gave up on (none, normally) from the retry list
+  auto launch_walk = [&](WalkArgs w, hipStream_t st) -> hipError_t {
+    w.key_base = w.lo;
+    const uint32_t n = w.hi - w.lo;
+    const int rc = b->sub_blocks && b->ctr_used + 3 <= b->d_ctr.n ? hnyk_walk_sub_rc(b->g, w, b->shape) : 0;
+    if (!rc) return hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
+    u32 *ctr = b->d_ctr.p + b->ctr_used;
+    b->ctr_used += 3;
+    WalkArgs s4 = w;
+    s4.queue = ctr;
+    s4.vtab = b->d_vtab.p;
+    s4.vtab_slots = b->vtab_slots;
+    s4.retry = b->d_retry.p;
+    s4.force_retry = (u32)std::max(0, env_int("HNY_SUB_FORCE_RETRY", 0)); // tests: hand over every n-th member
+    s4.n_retry = ctr + 1;
+    hipError_t rc2 = hnyk_walk_sub(b->g, s4, b->shape, rc, (int)std::min<uint32_t>((n + 3) / 4, b->sub_blocks), st);
+    if (rc2 != hipSuccess) return rc2;
+    WalkArgs r = w; // retry launch: queue index -> member through the retry list
+    r.lo = 0;
+    r.hi = 0;
+    r.hi_dev = ctr + 1;
+    r.perm = b->d_retry.p;
+    r.queue = ctr + 2;
+    return hnyk_walk(b->g, r, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
+  };
 
   const uint32_t cnt = hi - lo;
   if (L == 0 && b->overlap && cnt >= 8192) {
@@ -1094,7 +1157,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
       WalkArgs w = walk_args(0, clo, chi, queues + c);
       prof_begin(b, EV_WALK);
       b->n_walk_dispatch++;
-    HIP_TRY(hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(chi - clo, b->walk_slots), b->stream));
+    HIP_TRY(launch_walk(w, b->stream));
       prof_end(b);
       HIP_TRY(next_sync_event(b, &ev));
       HIP_TRY(hipEventRecord(ev, b->stream));
@@ -1114,14 +1177,13 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     // searches and prunes of every layer take the members in that order, so that the waves running
     // at the same time work in the same region of the graph and share candidate rows in L2 /
     // Infinity Cache.  Results are stored per member: the build is unchanged, only its memory traffic.
-    const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
     WalkArgs d = walk_args(L, lo, hi, queues + 0);
     d.descend_only = 1;
     d.eps_out = b->d_eps0.p;
     d.key_out = b->d_lkey_a.p;
     prof_begin(b, EV_WALK);
     b->n_walk_dispatch++;
-    HIP_TRY(hnyk_walk(b->g, d, b->shape, grid, b->stream));
+    HIP_TRY(launch_walk(d, b->stream));
     HIP_TRY(hnyk_iota_u64(b->d_perm_a.p, lo, cnt, b->stream));
     size_t tmp = b->sort_tmp_bytes;
     HIP_TRY(hnyk_sort_pairs48(b->d_sort_tmp.p, tmp, b->d_lkey_a.p, b->d_lkey_b.p, b->d_perm_a.p,
@@ -1136,7 +1198,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
       }
       w.perm = b->d_perm_b.p;
       b->n_walk_dispatch++;
-      HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+      HIP_TRY(launch_walk(w, b->stream));
       prof_end(b);
       PruneArgs p = prune_args(l, lo, hi);
       p.perm = b->d_perm_b.p;
@@ -1146,12 +1208,11 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     }
     return HNY_OK;
   }
-  const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
   for (int32_t l = (int32_t)L; l >= 0; l--) { // hnsw.rs:312-325
     WalkArgs w = walk_args(l, lo, hi, queues + l);
     prof_begin(b, EV_WALK);
     b->n_walk_dispatch++;
-    HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));
+    HIP_TRY(launch_walk(w, b->stream));
     prof_end(b);
     prof_begin(b, EV_PRUNE);
     HIP_TRY(launch_prune(prune_args(l, lo, hi), b->stream));
@@ -1430,6 +1491,9 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->entry_points = eps;
   g->n_entry_points = (uint32_t)b->entry_points.size();
   g->max_level = ml;
+  if (getenv("HNY_DEBUG_SUB"))
+    fprintf(stderr, "[hny] sub-wave walks %llu, handed over %llu (visited table full %llu, tie pool full %llu)\n",
+            stats[ST_SUB_DONE], stats[ST_SUB_RETRY], stats[ST_SUB_RETRY_VIS], stats[ST_SUB_RETRY_POOL]);
   if (getenv("HNY_DEBUG_COUNTS"))
     fprintf(stderr, "[hny] expansions %llu accepted %llu notfull %llu evals_walk %llu\n", stats[9], stats[10], stats[11],
             stats[ST_EVALS_WALK]);
@@ -1440,6 +1504,8 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->n_distance_evals = stats[ST_EVALS_WALK] + stats[ST_EVALS_PRUNE] + stats[ST_EVALS_APPLY];
   g->n_batches = b->n_batches;
   g->n_tie_pool_overflow = stats[ST_POOL_OVERFLOW];
+  g->n_sub_walks = stats[ST_SUB_DONE];
+  g->n_sub_retries = stats[ST_SUB_RETRY];
   g->t_upload_s = b->t_upload;
   g->t_build_s = b->t_build;
   g->t_export_s = now_s() - t0;

@@ -33,6 +33,10 @@ enum {
   ST_ERR_RES_OVERFLOW = 6,
   ST_ERR_ITER = 7,
   ST_ERR_GAPS_OVERFLOW = 8,
+  ST_SUB_DONE = 12,  // walks completed by k_walk_sub (four queries per wave)
+  ST_SUB_RETRY = 13, // walks k_walk_sub handed over to k_walk
+  ST_SUB_RETRY_VIS = 14,  // ... because the visited table filled up
+  ST_SUB_RETRY_POOL = 15, // ... because the tie pool filled up
   ST_COUNT = 16
 };
 
@@ -108,6 +112,15 @@ struct WalkArgs {
   u32 knn_ef;       // reader mode: opt.ef of the query builder
   u32 vis_slots;    // LDS visited table entries per wave (0: HBM bitset only)
   u32 eps_cap;      // LDS entries of the eps array: >= max(64, n_entry_points)
+  u32 key_base;     // key_out is indexed by member - key_base (== lo, except in a retry launch)
+  // k_walk_sub (four queries per wave, hny_walk_sub.h): per-query visited hash tables and the list of
+  // members it hands over to k_walk; k_walk's retry launch reads its member count from hi_dev
+  u32 *vtab;        // [grid * 4][vtab_slots], HNY_SENT = empty; every query leaves its table empty
+  u32 vtab_slots;   // power of two >= 512 (buckets of 16)
+  u64 *retry;       // members the sub-wave kernel gives up on
+  u32 force_retry;  // test hook: hand over every member with m % force_retry == 0
+  u32 *n_retry;
+  const u32 *hi_dev; // k_walk: hi = lo + *hi_dev (null: hi as given)
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -189,6 +202,11 @@ struct LaunchShape {
 
 // kernels' host launchers (hny_kernels.hip)
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
+// four queries per wave (rows <= 512 B, M0 <= 32, ef <= 127, <= 32 entry points, plain fresh build);
+// rc = 16-entry chunks of the register beam the launch needs (0: not eligible)
+int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s);
+hipError_t hnyk_walk_sub(const GraphDev &g, const WalkArgs &a, LaunchShape s, int rc, int grid, hipStream_t st);
+size_t hnyk_walk_sub_lds(int rc);
 hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
@@ -220,6 +238,8 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
 // the build kernels specialised for metric N-1 (hny_kernels.hip compiled with -DHNY_PART=N)
 #define HNY_DECL_SP(N)                                                                                      \
   hipError_t hnyk_walk_sp##N(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st); \
+  hipError_t hnyk_walk_sub_sp##N(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid,          \
+                                 hipStream_t st);                                                           \
   hipError_t hnyk_prune_wg_sp##N(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw,      \
                                  int grid, hipStream_t st);                                                 \
   hipError_t hnyk_apply_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,               \

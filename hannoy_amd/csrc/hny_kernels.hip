@@ -1103,6 +1103,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   WalkArgs a = a_in;
   specialize<SP>(g);
   if constexpr (SP != 0) a.reader_mode = RM ? 1 : 0; // RM: the Reader's search (hny_builder_search_knn)
+  if (a.hi_dev) a.hi = a.lo + *a.hi_dev; // retry launch behind k_walk_sub: the members it gave up on
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
@@ -1197,7 +1198,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     if (a.descend_only) { // (a batch whose level equals max_level has no greedy layer: eps stay)
       if (ln == 0) {
         a.eps_out[m] = eps[0];
-        a.key_out[m - a.lo] = lkey & 0xFFFFFFFFFFFFull;
+        a.key_out[m - a.key_base] = lkey & 0xFFFFFFFFFFFFull;
       }
       WSYNC();
       continue;
@@ -2547,6 +2548,8 @@ __global__ void k_fill_u32(u32 *p, u32 v, size_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+#include "hny_walk_sub.h"
+
 template <template <int, int> class Launcher, typename... Args>
 hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
 #define HNY_CASE(L, C) \
@@ -2601,6 +2604,28 @@ struct Hot {
       return hipGetLastError();
     }
   };
+  static hipError_t walk_sub(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid, hipStream_t st) {
+    if constexpr (SP == 0) {
+      return hipErrorInvalidValue;
+    } else {
+#define HNY_SUB_CASE(L, R)                                                                                   \
+  if (lpro == L && rc == R) {                                                                                \
+    hipLaunchKernelGGL((k_walk_sub<L, R, SP>), dim3(grid), dim3(64), walk_sub_lds_bytes(R), st, g, a);       \
+    return hipGetLastError();                                                                                \
+  }
+      HNY_SUB_CASE(8, 4)
+      HNY_SUB_CASE(8, 7)
+      HNY_SUB_CASE(8, 8)
+      HNY_SUB_CASE(16, 4)
+      HNY_SUB_CASE(16, 7)
+      HNY_SUB_CASE(16, 8)
+      HNY_SUB_CASE(32, 4)
+      HNY_SUB_CASE(32, 7)
+      HNY_SUB_CASE(32, 8)
+#undef HNY_SUB_CASE
+      return hipErrorInvalidValue;
+    }
+  }
   template <int L, int C>
   struct PruneWg {
     static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int nw, int grid, hipStream_t st) {
@@ -2701,6 +2726,10 @@ hipError_t HNY_CAT(hnyk_walk_sp, HNY_PART)(const GraphDev &g, const WalkArgs &a,
                                            hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::Walk>(s, g, a, grid, st);
 }
+hipError_t HNY_CAT(hnyk_walk_sub_sp, HNY_PART)(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid,
+                                               hipStream_t st) {
+  return Hot<HNY_PART>::walk_sub(g, a, lpro, rc, grid, st);
+}
 hipError_t HNY_CAT(hnyk_prune_wg_sp, HNY_PART)(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL,
                                                int nw, int grid, hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::PruneWg>(s, g, a, SL, nw, grid, st);
@@ -2740,6 +2769,21 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap) {
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
   if (fast_path(g) && a.eps_cap <= 64) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
   return dispatch_shape<Hot<0>::Walk>(s, g, a, grid, st);
+}
+int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s) {
+  // opt-in (HNY_SUB=1; read per launch: tests flip it inside one process): exact, but measured no faster
+  // than one wave per query — both issue the same ~35-45 VALU instructions per evaluation, because the
+  // O(ef) beam maintenance per expansion does not shrink with the lanes a query owns
+  const char *e = getenv("HNY_SUB");
+  if (!e || atoi(e) == 0) return 0;
+  if (!fast_path(g) || a.reader_mode || a.q_rows || s.nch != 1 || s.lpr > 32) return 0;
+  if (g.M0 > 32 || g.M > 32 || a.n_entry_points > 32 || a.cap_sel > 32) return 0;
+  const u32 need = a.ef > 32 ? a.ef : 32; // res holds max(ef, entry points) keys
+  return need <= 64 ? 4 : (need <= 112 ? 7 : (need <= 128 ? 8 : 0));
+}
+size_t hnyk_walk_sub_lds(int rc) { return walk_sub_lds_bytes(rc); }
+hipError_t hnyk_walk_sub(const GraphDev &g, const WalkArgs &a, LaunchShape s, int rc, int grid, hipStream_t st) {
+  HNY_SP_SWITCH(hnyk_walk_sub_sp, g, a, s.lpr, rc, grid, st)
 }
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<NnsFilteredLauncher>(s, g, a, grid, st);
