@@ -28,7 +28,7 @@ EXPORTED = [
     "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
     "hny_builder_nns", "hny_draw_levels_from_seed", "hny_builder_load",
     "hny_builder_apply_begin", "hny_builder_apply_deferred", "hny_builder_apply_merge",
-    "hny_builder_exch_stride_u64",
+    "hny_builder_exch_stride_u64", "hny_builder_stream",
     "hny_lmdb_writer_open", "hny_lmdb_writer_put", "hny_lmdb_writer_finish", "hny_lmdb_writer_abort",
     "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
 ]
@@ -70,7 +70,7 @@ class BuildOpts(C.Structure):
                 ("cancel", CANCEL_FN), ("cancel_ctx", C.c_void_p),
                 ("progress", PROGRESS_FN), ("progress_ctx", C.c_void_p),
                 ("batch_frac", C.c_double), ("batch_max", C.c_uint32), ("device", C.c_int32),
-                ("x86_order", C.c_int32)]
+                ("x86_order", C.c_int32), ("n_gpus", C.c_int32), ("devices", C.POINTER(C.c_int32))]
 
 
 class Items(C.Structure):
@@ -312,13 +312,19 @@ class ItemSet:
 
 
 def make_opts(metric, dim, M=16, M0=32, ef_construction=100, alpha=1.0, seed=42, batch_frac=0.0,
-              batch_max=0, device=-1, cancel=None, progress=None, x86_order=False):
+              batch_max=0, device=-1, cancel=None, progress=None, x86_order=False, n_gpus=0, devices=None):
     o = BuildOpts()
     o.metric, o.dim, o.M, o.M0 = metric, dim, M, M0
     o.ef_construction, o.alpha, o.seed = ef_construction, alpha, seed
     o.batch_frac, o.batch_max, o.device = batch_frac, batch_max, device
     o.x86_order = int(bool(x86_order))
     keep = []
+    o.n_gpus = int(n_gpus)
+    if devices is not None:  # one replica per listed GPU, RCCL all-gathers between them (hny_multi.cpp)
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        o.devices = C.cast(arr, C.POINTER(C.c_int32))
+        o.n_gpus = int(n_gpus) or len(devices)
+        keep.append(arr)
     if cancel is not None:
         fn = CANCEL_FN(lambda _ctx: 1 if cancel() else 0)
         o.cancel = fn
@@ -608,6 +614,14 @@ class Builder:
 
     def sync(self):
         _check(load_library().hny_builder_sync(self._h))
+
+    @property
+    def stream_ptr(self):
+        """hipStream_t every step is enqueued on (for collectives ordered on the same stream)"""
+        L = load_library()
+        L.hny_builder_stream.restype = C.c_void_p
+        L.hny_builder_stream.argtypes = [C.c_void_p]
+        return L.hny_builder_stream(self._h) or 0
 
     def run(self):
         """All batches on this GPU (what hny_build loops over)."""

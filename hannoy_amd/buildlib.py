@@ -6,9 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhannoy_amd.so")
-SOURCES = ["hny_host.cpp", "hny_kernels.hip", "hny_lmdb.cpp"]
+SOURCES = ["hny_host.cpp", "hny_multi.cpp", "hny_kernels.hip", "hny_lmdb.cpp"]
 HOST_ONLY = {"hny_lmdb.cpp"}  # no device code: compiled as plain C++
-HEADERS = [os.path.join(CSRC, "hny_internal.h"),
+HEADERS = [os.path.join(CSRC, "hny_internal.h"), os.path.join(CSRC, "hny_walk_sub.h"),
            os.path.join(os.path.dirname(HERE), "include", "hannoy_amd.h")]
 # -ffp-contract=off: FMAs only where the source says fmaf (parity with the oracle's orders);
 # correctly rounded f32 divide/sqrt for the cosine / hamming finalisers.
@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
     workers = max(1, min(len(jobs), int(os.environ.get("HNY_BUILD_JOBS", os.cpu_count() or 1))))
     with ThreadPoolExecutor(workers) as ex:
         objs = list(ex.map(run, jobs))
-    cmd = [hipcc(), "-shared", "--offload-arch=gfx950", "-o", LIB] + objs
+    cmd = [hipcc(), "-shared", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1358,6 +1358,8 @@ int hny_builder_set_profiling(hny_builder *b, int on) {
   return HNY_OK;
 }
 
+void *hny_builder_stream(hny_builder *b) { return b ? (void *)b->stream : nullptr; }
+
 int hny_builder_sync(hny_builder *b) {
   if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
   HIP_TRY(hipSetDevice(b->device));
@@ -1530,9 +1532,18 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   return HNY_OK;
 }
 
+extern "C" int hny_internal_build_multi(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
+                                        uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
+                                        const hny_prev_graph *prev, hny_graph **out); // hny_multi.cpp
+static bool wants_multi(const hny_build_opts *o) { return o && (o->n_gpus > 1 || (o->n_gpus == 1 && o->devices)); }
+
 int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **out) {
   if (!out) return fail(HNY_ERR_INVALID_ARG, "null out");
   *out = nullptr;
+  if (wants_multi(opts)) {
+    if (!items) return fail(HNY_ERR_INVALID_ARG, "null argument");
+    return hny_internal_build_multi(opts, items, nullptr, 0, nullptr, 0, nullptr, out);
+  }
   hny_builder *b = nullptr;
   int rc = hny_builder_create(opts, items, &b);
   if (rc) return rc;
@@ -1596,6 +1607,10 @@ int hny_build_incremental(const hny_build_opts *opts, const hny_items *items, co
                           const hny_prev_graph *prev, hny_graph **out) {
   if (!out) return fail(HNY_ERR_INVALID_ARG, "null out");
   *out = nullptr;
+  if (wants_multi(opts)) {
+    if (!items || !prev) return fail(HNY_ERR_INVALID_ARG, "null argument");
+    return hny_internal_build_multi(opts, items, to_insert, n_insert, to_delete, n_delete, prev, out);
+  }
   IncrementalSpec inc{to_insert, n_insert, to_delete, n_delete, prev};
   hny_builder *b = nullptr;
   int rc = create_impl(opts, items, &inc, &b);

@@ -1,0 +1,369 @@
+// hny_multi.cpp — the multi-GPU host of hny_build: what replaces the rayon loop of
+// /root/reference/src/hnsw.rs:172-185 (items of a level group inserted by a thread pool,
+// src/parallel.rs:11-45 handing every thread the vectors) when the build owns several MI355X of one
+// node (BASELINE north_star).
+//
+// One process, one host thread and one hny_builder per GPU; every GPU holds a full replica of the
+// vectors and of the graph.  Per batch, rank r runs walk_layer + robust_prune for a contiguous
+// slice of the members (hny_builder_search), the fixed-size selection records are exchanged with
+// ncclAllGather (RCCL over xGMI) ENQUEUED ON THE BUILDER'S OWN STREAM — no host synchronisation
+// between search, gather and the link phase — and every replica replays the same link ops in the
+// same order (hny_builder_apply_begin), which keeps the replicas bit-identical.  The targets whose
+// list overflows re-run robust_prune (hnsw.rs:547-552); they are split across the ranks too and
+// their finished lists travel in a second, small all-gather (hny_builder_apply_deferred / _merge).
+// The one host round trip per batch is the number of such targets (a 4-byte read).
+//
+// Written on top of the public stepwise C ABI only (include/hannoy_amd.h): a caller that wants its
+// own collectives can do exactly this.  RCCL is loaded with dlopen at the first multi-GPU build (the
+// library is 570 MB; a process that already holds an RCCL — PyTorch — shares that copy: same
+// soname), so single-GPU users never touch it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hannoy_amd.h"
+
+int hny_internal_fail(int code, const char *msg); // hny_host.cpp: sets hny_last_error()
+
+namespace {
+
+int failf(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return hny_internal_fail(code, buf);
+}
+
+// ---- RCCL entry points, resolved at run time
+struct Rccl {
+  void *handle = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+int load_rccl() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.handle) return HNY_OK;
+  void *h = nullptr;
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return failf(HNY_ERR_NO_DEVICE, "multi-GPU build: cannot load librccl (%s)", dlerror());
+  Rccl r;
+  r.handle = h;
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+  r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+    return failf(HNY_ERR_NO_DEVICE, "multi-GPU build: librccl lacks an expected symbol");
+  g_rccl = r;
+  return HNY_OK;
+}
+
+// ---- rendezvous of the per-GPU host threads
+class Barrier {
+ public:
+  explicit Barrier(int n) : n_(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    const uint64_t gen = gen_;
+    if (++arrived_ == n_) {
+      arrived_ = 0;
+      gen_++;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return gen_ != gen; });
+    }
+  }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int n_, arrived_ = 0;
+  uint64_t gen_ = 0;
+};
+
+struct Shared {
+  int world = 1;
+  Barrier bar;
+  std::vector<int> rc;             // one slot per rank, combined by agree()
+  std::vector<std::string> msg;
+  std::vector<void *> buf;         // shim exchange: every rank's buffer of the current collective
+  explicit Shared(int w) : world(w), bar(w), rc(w, 0), msg(w), buf(w, nullptr) {}
+  // every rank posts its status; all of them get the first error (or 0).  Called before each
+  // collective so that no rank waits inside one for a rank that has already failed.
+  int agree(int rank, int my_rc) {
+    rc[rank] = my_rc;
+    if (my_rc) msg[rank] = hny_last_error();
+    bar.wait();
+    int first = 0;
+    for (int r = 0; r < world && !first; r++) first = rc[r];
+    bar.wait();
+    return first;
+  }
+};
+
+// in-place all-gather of buf[rank * bytes .. (rank + 1) * bytes) on `st`
+struct Exchange {
+  virtual ~Exchange() {}
+  virtual int all_gather(int rank, void *buf, size_t bytes, hipStream_t st) = 0;
+};
+
+struct RcclExchange : Exchange {
+  std::vector<ncclComm_t> comms;
+  ~RcclExchange() override {
+    for (ncclComm_t c : comms)
+      if (c) (void)g_rccl.CommDestroy(c);
+  }
+  int init(const std::vector<int> &devices) {
+    if (int rc = load_rccl()) return rc;
+    comms.assign(devices.size(), nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data());
+    if (r != ncclSuccess) {
+      comms.clear();
+      return failf(HNY_ERR_NO_DEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString(r));
+    }
+    return HNY_OK;
+  }
+  int all_gather(int rank, void *buf, size_t bytes, hipStream_t st) override {
+    if (!bytes) return HNY_OK;
+    ncclResult_t r = g_rccl.AllGather((const char *)buf + (size_t)rank * bytes, buf, bytes, ncclUint8, comms[rank], st);
+    if (r != ncclSuccess) return failf(HNY_ERR_DEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(r));
+    return HNY_OK;
+  }
+};
+
+// Test shim (HNY_MGPU_SHIM=1): the same driver with the collective replaced by device-to-device
+// copies between the builders' buffers and a host rendezvous, so that several "ranks" can share one
+// GPU (RCCL refuses duplicate devices).  Exercises everything but RCCL itself.
+struct ShimExchange : Exchange {
+  Shared *sh;
+  explicit ShimExchange(Shared *s) : sh(s) {}
+  int all_gather(int rank, void *buf, size_t bytes, hipStream_t st) override {
+    hipError_t e = hipStreamSynchronize(st); // my slice is complete
+    sh->buf[rank] = buf;
+    sh->bar.wait();
+    for (int r = 0; r < sh->world && e == hipSuccess; r++)
+      if (r != rank && bytes)
+        e = hipMemcpyAsync((char *)buf + (size_t)r * bytes, (const char *)sh->buf[r] + (size_t)r * bytes, bytes,
+                           hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    sh->bar.wait(); // nobody reuses a buffer a peer is still reading
+    if (e != hipSuccess) return failf(HNY_ERR_DEVICE, "shim all-gather: %s", hipGetErrorString(e));
+    return HNY_OK;
+  }
+};
+
+struct DevMem {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return HNY_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    need += need / 4;
+    if (hipMalloc(&p, need) != hipSuccess) return failf(HNY_ERR_OOM, "multi-GPU build: exchange buffer of %zu bytes", need);
+    bytes = need;
+    return HNY_OK;
+  }
+  ~DevMem() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+struct Job {
+  const hny_build_opts *opts;
+  const hny_items *items;
+  const uint32_t *to_insert, *to_delete;
+  uint64_t n_insert, n_delete;
+  const hny_prev_graph *prev; // null: fresh build
+};
+
+// the batch loop of one rank (hny_build's loop with the two exchanges in it)
+int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny_graph **out, uint64_t *checksum) {
+  const int world = sh.world;
+  hny_build_opts o = *job.opts;
+  o.device = device;
+  o.n_gpus = 0;
+  o.devices = nullptr;
+  if (rank != 0) { // callbacks fire on rank 0 only
+    o.cancel = nullptr;
+    o.progress = nullptr;
+  }
+  hny_builder *b = nullptr;
+  int rc = job.prev ? hny_builder_create_incremental(&o, job.items, job.to_insert, job.n_insert, job.to_delete,
+                                                     job.n_delete, job.prev, &b)
+                    : hny_builder_create(&o, job.items, &b);
+  std::unique_ptr<hny_builder, void (*)(hny_builder *)> guard(b, hny_builder_destroy);
+  rc = sh.agree(rank, rc);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)hny_builder_stream(b);
+  (void)hipSetDevice(device);
+  DevMem sel, exch;
+  const uint32_t min_shard = (uint32_t)std::max(1, env_int("HNY_MGPU_MIN_BATCH", 64 * world));
+  const uint32_t min_def = (uint32_t)std::max(1, env_int("HNY_MGPU_MIN_DEFERRED", 32 * world));
+  const uint32_t xs = hny_builder_exch_stride_u64(b);
+  uint64_t done = 0, total = 0;
+  for (;;) {
+    int cancelled = 0;
+    if (job.opts->cancel) { // polled by rank 0 before every batch, obeyed by all (lib.rs:140)
+      if (rank == 0) cancelled = job.opts->cancel(job.opts->cancel_ctx) ? HNY_ERR_CANCELLED : 0;
+      if (rank == 0 && cancelled) (void)failf(HNY_ERR_CANCELLED, "build cancelled");
+      cancelled = sh.agree(rank, cancelled);
+      if (cancelled) return cancelled;
+    }
+    hny_batch bt;
+    rc = hny_builder_next_batch(b, &bt);
+    if (rc) return sh.agree(rank, rc);
+    if (bt.count == 0) break;
+    if (bt.count < min_shard) { // ramp-up: the exchange would cost more than the search
+      rc = hny_builder_search(b, 0, bt.count, nullptr);
+      if (!rc) rc = hny_builder_apply(b, nullptr);
+      if (rc) return sh.agree(rank, rc);
+    } else {
+      const uint32_t per = (bt.count + (uint32_t)world - 1) / (uint32_t)world;
+      const uint32_t lo = std::min<uint32_t>((uint32_t)rank * per, bt.count), hi = std::min<uint32_t>(lo + per, bt.count);
+      const size_t words = (size_t)world * per * bt.sel_stride_u64;
+      rc = sel.ensure(words * 8);
+      if (!rc) rc = hny_builder_search(b, lo, hi, sel.p);
+      rc = sh.agree(rank, rc);
+      if (rc) return rc;
+      rc = ex.all_gather(rank, sel.p, (size_t)per * bt.sel_stride_u64 * 8, st);
+      uint32_t nd = 0;
+      if (!rc) rc = hny_builder_apply_begin(b, sel.p, &nd); // the same number on every rank
+      if (!rc && nd < min_def) {
+        rc = hny_builder_apply_deferred(b, 0, 1, nullptr);
+        if (!rc) rc = hny_builder_apply_merge(b, nullptr, 0, 1);
+        if (rc) return sh.agree(rank, rc);
+      } else {
+        const uint32_t per2 = (nd + (uint32_t)world - 1) / (uint32_t)world;
+        if (!rc) rc = exch.ensure((size_t)world * per2 * xs * 8);
+        if (!rc) rc = hny_builder_apply_deferred(b, (uint32_t)rank, (uint32_t)world, exch.p);
+        rc = sh.agree(rank, rc);
+        if (rc) return rc;
+        rc = ex.all_gather(rank, exch.p, (size_t)per2 * xs * 8, st);
+        if (!rc) rc = hny_builder_apply_merge(b, exch.p, (uint32_t)rank, (uint32_t)world);
+        if (rc) return sh.agree(rank, rc);
+      }
+    }
+    done += bt.count;
+    if (rank == 0 && job.opts->progress) {
+      if (!total) total = job.prev ? done : job.items->n;
+      job.opts->progress(job.opts->progress_ctx, done, std::max(total, done));
+    }
+  }
+  if (job.prev) { // fill_gaps_from_deleted (hnsw.rs:187): deterministic, every replica does it
+    rc = hny_builder_fill_gaps(b);
+    if (rc) return sh.agree(rank, rc);
+  }
+  rc = sh.agree(rank, 0);
+  if (rc) return rc;
+  const bool verify = env_int("HNY_MGPU_VERIFY", 0) != 0;
+  if (rank == 0 || verify) {
+    hny_graph *g = nullptr;
+    rc = hny_builder_finish(b, &g);
+    if (!rc && checksum) { // FNV-1a over the exported lists: replicas must agree
+      uint64_t h = 1469598103934665603ull;
+      const uint64_t nl = g->rec_offset[g->n_records];
+      for (uint64_t i = 0; i < nl; i++) h = (h ^ g->neighbours[i]) * 1099511628211ull;
+      for (uint64_t i = 0; i <= g->n_records; i++) h = (h ^ g->rec_offset[i]) * 1099511628211ull;
+      *checksum = h;
+    }
+    if (rank == 0 && !rc)
+      *out = g;
+    else
+      hny_graph_free(g);
+  } else {
+    rc = hny_builder_sync(b);
+  }
+  return rc;
+}
+
+} // namespace
+
+extern "C" int hny_internal_build_multi(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
+                                        uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
+                                        const hny_prev_graph *prev, hny_graph **out) {
+  *out = nullptr;
+  const int world = opts->n_gpus;
+  if (world < 1 || world > 64) return failf(HNY_ERR_INVALID_ARG, "n_gpus %d outside [1, 64]", world);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return failf(HNY_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+  std::vector<int> devices(world);
+  for (int r = 0; r < world; r++) {
+    devices[r] = opts->devices ? opts->devices[r] : r;
+    if (devices[r] < 0 || devices[r] >= ndev)
+      return failf(HNY_ERR_NO_DEVICE, "device %d of rank %d: %d devices visible", devices[r], r, ndev);
+  }
+  const bool shim = env_int("HNY_MGPU_SHIM", 0) != 0;
+  if (!shim)
+    for (int r = 0; r < world; r++)
+      for (int q = 0; q < r; q++)
+        if (devices[q] == devices[r]) return failf(HNY_ERR_INVALID_ARG, "device %d listed twice", devices[r]);
+  Shared sh(world);
+  std::unique_ptr<Exchange> ex;
+  if (shim) {
+    ex.reset(new ShimExchange(&sh));
+  } else {
+    std::unique_ptr<RcclExchange> rx(new RcclExchange());
+    if (int rc = rx->init(devices)) return rc;
+    ex = std::move(rx);
+  }
+  Job job{opts, items, to_insert, to_delete, n_insert, n_delete, prev};
+  std::vector<int> rcs(world, 0);
+  std::vector<std::string> msgs(world);
+  std::vector<uint64_t> sums(world, 0);
+  std::vector<std::thread> th;
+  for (int r = 1; r < world; r++)
+    th.emplace_back([&, r]() {
+      rcs[r] = run_rank(r, devices[r], job, sh, *ex, out, &sums[r]);
+      if (rcs[r]) msgs[r] = hny_last_error();
+    });
+  rcs[0] = run_rank(0, devices[0], job, sh, *ex, out, &sums[0]); // callbacks run on the caller's thread
+  if (rcs[0]) msgs[0] = hny_last_error();
+  for (auto &t : th) t.join();
+  for (int r = 0; r < world; r++)
+    if (rcs[r]) {
+      if (*out) hny_graph_free(*out);
+      *out = nullptr;
+      // the rank that failed first holds the message (the others report "a peer failed")
+      for (int q = 0; q < world; q++)
+        if (!sh.msg[q].empty()) return hny_internal_fail(sh.rc[q] ? sh.rc[q] : rcs[r], sh.msg[q].c_str());
+      return hny_internal_fail(rcs[r], msgs[r].empty() ? "multi-GPU build failed" : msgs[r].c_str());
+    }
+  if (env_int("HNY_MGPU_VERIFY", 0))
+    for (int r = 1; r < world; r++)
+      if (sums[r] != sums[0]) {
+        hny_graph_free(*out);
+        *out = nullptr;
+        return failf(HNY_ERR_DEVICE, "replicas diverged: rank %d exports a different graph than rank 0", r);
+      }
+  return HNY_OK;
+}

@@ -9,7 +9,14 @@ phase's time): those are split across the ranks as well (hny_builder_apply_begin
 _merge) and their finished lists exchanged with a second, small all-gather (272 B per target at
 M0=32, a few MB per batch).  Small batches (the ramp-up) are computed redundantly by every rank
 instead: the exchange would cost more than the search.
+
+This is the torchrun harness (one PROCESS per GPU, what bench.py --gpus N runs); the same protocol
+inside one process — one host thread per GPU, RCCL called directly — is hny_multi.cpp behind
+hny_build(n_gpus=N).  On the RCCL path the collectives are issued with the builder's own HIP stream
+as torch's current stream, so search -> all-gather -> apply are ordered on the device and the only
+host round trip per batch is the deferred-target count.
 """
+import contextlib
 import math
 
 
@@ -28,10 +35,19 @@ class Driver:
         # shard the deferred re-prunes of the apply phase too (needs the three-step apply of the C ABI)
         self.shard_apply = hasattr(builder, "apply_begin") if shard_apply is None else shard_apply
         self.min_shard_deferred = 32 * world if min_shard_deferred is None else min_shard_deferred
+        # RCCL path: make the builder's stream torch's current stream around the collectives
+        self._ext = None
+        if (dist is not None and not host_staged and getattr(device, "type", "cpu") == "cuda"
+                and getattr(builder, "stream_ptr", 0)):
+            self._ext = torch.cuda.ExternalStream(builder.stream_ptr, device=device)
+
+    def _on_builder_stream(self):
+        return self.torch.cuda.stream(self._ext) if self._ext is not None else contextlib.nullcontext()
 
     def _buffer(self, words):
         if self._buf is None or self._buf.numel() < words:
-            self._buf = self.torch.empty(words, dtype=self.torch.int64, device=self.device)
+            self.b.sync()  # the old buffer may still be in use on the builder's stream
+            self._buf = self.torch.empty(words + words // 4, dtype=self.torch.int64, device=self.device)
         return self._buf
 
     @staticmethod
@@ -59,16 +75,7 @@ class Driver:
             stride = bt.sel_stride_u64
             full = self._buffer(self.world * per * stride)
             b.search(lo, hi, full.data_ptr())
-            b.sync()  # the builder runs on its own HIP stream
-            mine = full[self.rank * per * stride:(self.rank + 1) * per * stride].clone()
-            if self.host_staged:
-                gathered = self.torch.empty(self.world * per * stride, dtype=self.torch.int64)
-                self.dist.all_gather_into_tensor(gathered, mine.cpu())
-                full[:self.world * per * stride].copy_(gathered)
-            else:
-                self.dist.all_gather_into_tensor(full[:self.world * per * stride], mine)
-            self.n_collectives += 1
-            self._sync_collective()
+            self._all_gather(full, per * stride)
             if not self.shard_apply:
                 b.apply(full.data_ptr())
                 continue
@@ -80,10 +87,10 @@ class Driver:
             xs = b.exch_stride_u64
             per2 = math.ceil(nd / self.world)
             if self._buf2 is None or self._buf2.numel() < self.world * per2 * xs:
-                self._buf2 = self.torch.empty(self.world * per2 * xs, dtype=self.torch.int64, device=self.device)
+                b.sync()
+                self._buf2 = self.torch.empty(self.world * per2 * xs * 2, dtype=self.torch.int64, device=self.device)
             ex = self._buf2
             b.apply_deferred(self.rank, self.world, ex.data_ptr())
-            b.sync()
             self._all_gather(ex, per2 * xs)
             b.apply_merge(ex.data_ptr(), self.rank, self.world)
         if getattr(b, "incremental", False):  # fill_gaps_from_deleted (hnsw.rs:187): deterministic,
@@ -91,17 +98,25 @@ class Driver:
         return n
 
     def _all_gather(self, full, words_per_rank):
-        """in-place all-gather of `full[rank * w : (rank + 1) * w]` (w = words_per_rank)"""
+        """in-place all-gather of `full[rank * w : (rank + 1) * w]` (w = words_per_rank), ordered
+        after the builder's pending work and before its next step"""
         w = words_per_rank
-        mine = full[self.rank * w:(self.rank + 1) * w].clone()
-        if self.host_staged:
-            gathered = self.torch.empty(self.world * w, dtype=self.torch.int64)
-            self.dist.all_gather_into_tensor(gathered, mine.cpu())
-            full[:self.world * w].copy_(gathered)
-        else:
+        if self.host_staged or self._ext is None:
+            self.b.sync()  # the builder runs on its own HIP stream
+            mine = full[self.rank * w:(self.rank + 1) * w].clone()
+            if self.host_staged:
+                gathered = self.torch.empty(self.world * w, dtype=self.torch.int64)
+                self.dist.all_gather_into_tensor(gathered, mine.cpu())
+                full[:self.world * w].copy_(gathered)
+            else:
+                self.dist.all_gather_into_tensor(full[:self.world * w], mine)
+            self.n_collectives += 1
+            self._sync_collective()
+            return
+        with self._on_builder_stream():  # no host synchronisation: stream order does it
+            mine = full[self.rank * w:(self.rank + 1) * w].clone()
             self.dist.all_gather_into_tensor(full[:self.world * w], mine)
         self.n_collectives += 1
-        self._sync_collective()
 
     def _sync_collective(self):
         if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":

@@ -73,6 +73,13 @@ typedef struct {
    * batch_max = 1 the build then equals the reference run with one thread.  0 = wave order
    * (within 1e-5 relative of it). */
   int32_t x86_order;
+  /* replaces: the rayon pool of the insert loop (hnsw.rs:172-185).  n_gpus > 1, or n_gpus == 1 with
+   * `devices` given: hny_build / hny_build_incremental run one replica per listed GPU of this node
+   * (devices == NULL: ordinals 0 .. n_gpus-1; `device` is ignored), shard every batch's searches
+   * across them and exchange the results with RCCL all-gathers over xGMI (hny_multi.cpp).  The
+   * result is byte for byte the n_gpus == 1 result.  0 / 1 without `devices`: one GPU, no RCCL. */
+  int32_t n_gpus;
+  const int32_t *devices;
 } hny_build_opts;
 
 /* replaces: what FrozenReader hands to the builder (src/parallel.rs:33-45) */
@@ -182,6 +189,9 @@ int hny_builder_apply_deferred(hny_builder *b, uint32_t rank, uint32_t world, vo
 int hny_builder_apply_merge(hny_builder *b, const void *exch_all_dev, uint32_t rank, uint32_t world);
 uint32_t hny_builder_exch_stride_u64(const hny_builder *b);
 int hny_builder_sync(hny_builder *b);
+/* the HIP stream (hipStream_t) every step above is enqueued on: a multi-GPU driver puts its
+ * collectives on it, so that search -> all-gather -> apply need no host synchronisation */
+void *hny_builder_stream(hny_builder *b);
 /* record a HIP event pair around every kernel family launch (bench roofline accounting) */
 int hny_builder_set_profiling(hny_builder *b, int on);
 int hny_builder_finish(hny_builder *b, hny_graph **out);

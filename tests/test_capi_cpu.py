@@ -38,6 +38,13 @@ def test_no_cpu_fallback(hny):
     with pytest.raises(hny.HannoyError) as e:
         hny.build(items)
     assert e.value.code == -6  # HNY_ERR_NO_DEVICE
+    # the multi-GPU host (hny_multi.cpp) fails just as loudly, before it touches RCCL
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items, n_gpus=2)
+    assert e.value.code == -6
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items, n_gpus=100)
+    assert e.value.code == -1
 
 
 def test_argument_validation(hny):

@@ -970,3 +970,76 @@ def test_every_item_an_entry_point(orc, hny, metric, n, dim):
     og2 = orc.build_incremental(ds2, og, to_insert, ins_lv, to_delete, **kw_o)
     gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
     _same_graph(gg2, og2)
+
+
+def _multi_case(orc, hny, metric=0, n=9000, dim=96, M=8, M0=16, ef=48):
+    rng = np.random.default_rng(77 + metric)
+    cent = rng.uniform(-1, 1, (24, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 24, n)] + 0.25 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=6))
+    kw = dict(M=M, M0=M0, batch_frac=1.0, batch_max=2048)
+    o = orc.build(ds, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    return ds, items, o, dict(ef_construction=ef, **kw)
+
+
+def test_native_multi_gpu_driver_one_rank_over_rccl(orc, hny):
+    """hny_build(n_gpus=1, devices=[0]) takes the multi-GPU host of hny_multi.cpp with a REAL RCCL
+    communicator of size one (ncclCommInitAll + ncclAllGather on the builder's stream, both
+    exchanges of every batch): byte for byte the plain build, which equals the oracle."""
+    ds, items, o, kw = _multi_case(orc, hny)
+    os.environ["HNY_MGPU_MIN_BATCH"] = "8"
+    os.environ["HNY_MGPU_MIN_DEFERRED"] = "1"
+    try:
+        g = hny.build(items, n_gpus=1, devices=[0], **kw)
+    finally:
+        del os.environ["HNY_MGPU_MIN_BATCH"], os.environ["HNY_MGPU_MIN_DEFERRED"]
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+    g1 = hny.build(items, **kw)
+    _same_graph(g1, g)
+
+
+@pytest.mark.parametrize("world,metric", [(2, 0), (3, 3), (4, 1)])
+def test_native_multi_gpu_driver_ranks_share_one_gpu(orc, hny, monkeypatch, world, metric):
+    """The native driver with `world` ranks mapped to ONE GPU (HNY_MGPU_SHIM=1: the collective is
+    replaced by device-to-device copies between the ranks' buffers + a host rendezvous, because RCCL
+    refuses duplicate devices): sharded searches, sharded deferred re-prunes, both exchanges, one host
+    thread per rank.  Every replica must export the oracle's graph (HNY_MGPU_VERIFY compares them)."""
+    monkeypatch.setenv("HNY_MGPU_SHIM", "1")
+    monkeypatch.setenv("HNY_MGPU_VERIFY", "1")
+    monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "16")
+    monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
+    ds, items, o, kw = _multi_case(orc, hny, metric=metric, dim=96 if metric < 3 else 512)
+    seen = []
+    g = hny.build(items, devices=[0] * world, progress=lambda d, t: seen.append((d, t)), **kw)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added
+    assert seen and seen[-1][0] == len(ds.ids)
+    with pytest.raises(hny.BuildCancelled):
+        hny.build(items, devices=[0] * world, cancel=lambda: len(seen) > 0, **kw)
+
+
+def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
+    """hny_build_incremental through the native driver (two ranks on one GPU): deletes + inserts on
+    top of a stored graph, fill_gaps_from_deleted on every replica, == oracle."""
+    monkeypatch.setenv("HNY_MGPU_SHIM", "1")
+    monkeypatch.setenv("HNY_MGPU_VERIFY", "1")
+    monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "16")
+    rng = np.random.default_rng(5)
+    n, dim, M, M0, ef = 3000, 32, 8, 16, 40
+    vecs = rng.uniform(-1, 1, (n + 600, dim)).astype(np.float32)
+    kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=0.5, batch_max=512)
+    kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=0.5, batch_max=512)
+    ds, items = _mk(orc, hny, 1, vecs[:n], draw_levels(n, M, seed=8))
+    og = orc.build(ds, threads=8, **kw_o)
+    gg = hny.build(items, devices=[0, 0], **kw_g)
+    _same_graph(gg, og)
+    to_delete = np.sort(rng.choice(n, 300, replace=False)).astype(np.uint32)
+    alive = np.setdiff1d(np.arange(n + 600, dtype=np.uint32), to_delete)
+    to_insert = np.arange(n, n + 600, dtype=np.uint32)
+    lv = draw_levels(600, M, seed=9)
+    ds2 = orc.Dataset.from_f32(1, vecs[alive], np.zeros(len(alive), np.uint8), alive)
+    items2 = hny.ItemSet(1, dim, ds2.ids, ds2.codes, ds2.headers, lv)
+    og2 = orc.build_incremental(ds2, og, to_insert, lv, to_delete, **kw_o)
+    gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, devices=[0, 0], **kw_g)
+    _same_graph(gg2, og2)
