@@ -36,7 +36,13 @@ def parse():
     p.add_argument("--M", type=int, default=16)
     p.add_argument("--M0", type=int, default=0)
     p.add_argument("--ef", type=int, default=100)
-    p.add_argument("--data", default="clustered", choices=["clustered", "uniform"])
+    p.add_argument("--data", default="clustered", choices=["clustered", "overlap", "uniform"])
+    p.add_argument("--alt-data", default=None, choices=["overlap", "uniform", "clustered", "none"],
+                   help="second distribution measured in the same run (value_alt / roofline_alt); default: "
+                        "`overlap` for the default C2 run on one GPU, none otherwise")
+    p.add_argument("--alt-steps", type=int, default=2)
+    p.add_argument("--cpu-full", action="store_true",
+                   help="time the CPU baseline on ALL vectors (about 80-100 s at C2) instead of a bounded sample")
     p.add_argument("--batch-frac", type=float, default=0.0)
     p.add_argument("--batch-max", type=int, default=0)
     p.add_argument("--queries", type=int, default=1000)
@@ -54,17 +60,34 @@ def parse():
     return p.parse_args()
 
 
-def gen_data(torch, n, dim, kind, seed, device):
-    """Synthetic vectors, generated on the GPU (counter-based Philox -> identical on every rank)."""
+def gen_data(torch, n, dim, kind, seed, device, queries=False):
+    """Synthetic vectors, generated on the GPU (counter-based Philox -> identical on every rank).
+    queries=True: held-out points of the SAME distribution (same centres / basis, fresh noise)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    g2 = torch.Generator(device=device)
+    g2.manual_seed(seed + 1000)
+    gn = g2 if queries else g  # the structure (centres, basis) always comes from `g`
     if kind == "uniform":  # reference-style U(-1,1) (src/tests/mod.rs:133-136)
-        x = torch.rand((n, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1
-    else:  # 1024-centre Gaussian mixture, centres U(-1,1), sigma 0.15 (BASELINE.md C2 (ii))
-        centres = torch.rand((1024, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1
-        which = torch.randint(0, 1024, (n,), generator=g, device=device)
-        x = centres[which] + 0.15 * torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
-    return x
+        return torch.rand((n, dim), generator=gn, device=device, dtype=torch.float32) * 2 - 1
+    if kind == "overlap":
+        # embedding-like: 1 024 OVERLAPPING clusters on a 32-d manifold embedded in `dim` dimensions
+        # (latent centres N(0, 1), points centre + 0.5 N(0, 1): the spread inside a cluster is half the
+        # spread of the centres, so neighbourhoods cross cluster borders) + 0.05 isotropic noise
+        k = min(32, dim)
+        centres = torch.randn((1024, k), generator=g, device=device, dtype=torch.float32)
+        basis = torch.linalg.qr(torch.randn((dim, k), generator=g, device=device, dtype=torch.float32))[0].T
+        which = torch.randint(0, 1024, (n,), generator=gn, device=device)
+        out = torch.empty((n, dim), device=device, dtype=torch.float32)
+        for lo in range(0, n, 1 << 18):  # in slices: bounded temporaries
+            hi = min(n, lo + (1 << 18))
+            z = centres[which[lo:hi]] + 0.5 * torch.randn((hi - lo, k), generator=gn, device=device)
+            out[lo:hi] = z @ basis + 0.05 * torch.randn((hi - lo, dim), generator=gn, device=device)
+        return out
+    # 1024-centre Gaussian mixture, centres U(-1,1), sigma 0.15 (BASELINE.md C2 (ii)): well separated
+    centres = torch.rand((1024, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1
+    which = torch.randint(0, 1024, (n,), generator=gn, device=device)
+    return centres[which] + 0.15 * torch.randn((n, dim), generator=gn, device=device, dtype=torch.float32)
 
 
 def brute_force_topk(torch, metric, data, queries, k):
@@ -121,92 +144,117 @@ def main():
 
     # ---- synthetic data (+ held-out queries from the same distribution) ----
     x_dev = gen_data(torch, a.n, a.dim, a.data, a.seed, dev)
-    q_dev = gen_data(torch, a.queries, a.dim, a.data, a.seed + 1000, dev) if a.queries else None
-    if a.data == "clustered" and a.queries:  # queries: fresh noise around the SAME centres
-        g = torch.Generator(device=dev)
-        g.manual_seed(a.seed)
-        centres = torch.rand((1024, a.dim), generator=g, device=dev, dtype=torch.float32) * 2 - 1
-        g2 = torch.Generator(device=dev)
-        g2.manual_seed(a.seed + 1000)
-        which = torch.randint(0, 1024, (a.queries,), generator=g2, device=dev)
-        q_dev = centres[which] + 0.15 * torch.randn((a.queries, a.dim), generator=g2, device=dev)
+    q_dev = gen_data(torch, a.queries, a.dim, a.data, a.seed, dev, queries=True) if a.queries else None
     x = x_dev.cpu().numpy()
     items = H.ItemSet.from_f32(metric, x)
     row_bytes = items.codes.shape[1]
     bytes_per_eval = row_bytes + items.headers.shape[1]  # row + header
 
-    builder = H.Builder(items, M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed,
-                        batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank,
-                        x86_order=a.x86_order)
-    builder.set_profiling(True)
-    driver = multigpu.Driver(builder, torch, dist if world > 1 else None, rank, world, dev,
-                             host_staged=(a.backend == "gloo"))
+    def timed_builds(items_, steps, warmup):
+        """W untimed + K timed full builds (graph reset -> every batch -> records exported)."""
+        b = H.Builder(items_, M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed,
+                      batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank,
+                      x86_order=a.x86_order)
+        b.set_profiling(True)
+        drv = multigpu.Driver(b, torch, dist if world > 1 else None, rank, world, dev,
+                              host_staged=(a.backend == "gloo"))
 
-    def step():
-        builder.reset()
-        driver.run()
-        return builder.finish()
+        def step():
+            b.reset()
+            drv.run()
+            return b.finish()
 
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    graph = None
-    for _ in range(a.steps):
-        graph = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if graph is None:
-        graph = step()
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = None
+        for _ in range(steps):
+            g = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        if g is None:
+            g = step()
+        return b, drv, g, dt_
+
+    def roofline_of(g, dt_, steps):
+        """dominant kernel (k_walk): algorithmic bytes / device time, HIP events on the builder's
+        stream around every k_walk dispatch (a level-0 batch: descent dispatch + key sort + layer-0
+        dispatch under one pair); `launches` = k_walk dispatches, what rocprofv3 counts"""
+        wb = g.n_evals_walk * bytes_per_eval
+        if g.t_walk_kernels_s <= 0:
+            return None
+        ach = wb / g.t_walk_kernels_s / 1e9
+        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_walk",
+             "launches": int(g.n_walk_launches),
+             "avg_launch_ms": round(1e3 * g.t_walk_kernels_s / max(1, g.n_walk_launches), 4),
+             "algorithmic_bytes_per_launch": int(wb / max(1, g.n_walk_launches)),
+             "bytes_per_eval": bytes_per_eval}
+        if steps:  # the same bytes over the WHOLE step (prune, link ops, export included)
+            r["frac_whole_build"] = round(wb / (dt_ / steps) / 1e9 / HBM_PEAK_GBS, 4)
+        return r
+
+    def build_stats(g):
+        return {"n_batches": int(g.n_batches), "n_distance_evals": int(g.n_distance_evals),
+                "evals_walk": int(g.n_evals_walk), "evals_prune": int(g.n_evals_prune),
+                "evals_apply": int(g.n_evals_apply), "links_added": int(g.n_links_added),
+                "t_build_s": round(g.t_build_s, 3), "t_export_s": round(g.t_export_s, 3),
+                "t_upload_s": round(g.t_upload_s, 3),
+                "t_walk_kernels_s": round(g.t_walk_kernels_s, 3),
+                "t_prune_kernels_s": round(g.t_prune_kernels_s, 3),
+                "t_sort_kernels_s": round(g.t_sort_kernels_s, 3),
+                "t_apply_kernels_s": round(g.t_apply_kernels_s, 3),
+                "tie_pool_overflow": int(g.n_tie_pool_overflow),
+                "sub_wave_walks": int(g.n_sub_walks), "sub_wave_handed_over": int(g.n_sub_retries)}
+
+    builder, driver, graph, dt = timed_builds(items, a.steps, a.warmup)
     value = a.n * a.steps / dt if a.steps else 0.0
+    roof = roofline_of(graph, dt, a.steps)
 
-    # ---- roofline of the dominant kernel (k_walk): algorithmic bytes / device time, HIP events on
-    # the builder's stream around every k_walk dispatch (a level-0 batch: descent dispatch + key sort +
-    # layer-0 dispatch under one pair); `launches` = k_walk dispatches, what rocprofv3 counts ----
-    walk_bytes = graph.n_evals_walk * bytes_per_eval
-    roof = None
-    if graph.t_walk_kernels_s > 0:
-        ach = walk_bytes / graph.t_walk_kernels_s / 1e9
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_walk",
-                "launches": int(graph.n_walk_launches),
-                "avg_launch_ms": round(1e3 * graph.t_walk_kernels_s / max(1, graph.n_walk_launches), 4),
-                "algorithmic_bytes_per_launch": int(walk_bytes / max(1, graph.n_walk_launches)),
-                "bytes_per_eval": bytes_per_eval}
-
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-    # the figure comes from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch
-    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm_specialised.json")
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process,
+    # so the figure comes from the committed rocprofv3 --pmc passes of this same command
+    # (scripts/profile_c2.sh; FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch.
+    # The profile records the hash of the kernel source it was taken on: a mismatch is flagged.
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
                   and world == 1 and not a.x86_order)
-    if roof and default_c2 and os.path.exists(pmc_file):
-        with open(pmc_file) as f:
-            pk = json.load(f).get("k_walk")
+    pmc_name = next((f for f in ("r02_c2_pmc_hbm.json", "r01_c2_pmc_hbm_specialised.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    if roof and default_c2 and pmc_name:
+        with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
+            pj = json.load(f)
+        pk = pj.get("k_walk")
         if pk:
             total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
             roof["traffic"] = int(total / max(1, pk["launches"]))
-            roof["traffic_source"] = ("profiles/r01_c2_pmc_hbm_specialised.json: rocprofv3 --pmc FETCH_SIZE / "
-                                      "WRITE_SIZE passes of this command (scripts/profile_c2.sh), 2x FETCH + "
-                                      f"WRITE summed over the {pk['launches']} k_walk dispatches of one build, "
-                                      "per dispatch; FETCH_SIZE counts Infinity-Cache hits too, so this is "
-                                      "L2-to-fabric traffic, an upper bound on HBM")
+            # FETCH_SIZE counts what the Infinity Cache serves too: this is L2-to-fabric traffic (an upper
+            # bound on HBM), and `achieved` above is algorithmic bytes (it also credits L2 hits)
+            roof["l2_to_fabric_gbs"] = round(roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1)
+            import hashlib
+            with open(os.path.join(ROOT, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb") as f:
+                sha = hashlib.sha1(f.read()).hexdigest()
+            roof["traffic_source"] = (f"profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      f"command (scripts/profile_c2.sh), 2x FETCH + WRITE summed over the "
+                                      f"{pk['launches']} k_walk dispatches of one build, per dispatch")
+            roof["traffic_stale"] = pj.get("kernel_source_sha1") != sha  # kernels changed since the PMC passes
 
     known = {(1_000_000, 768, "cosine", 16, 100): "C2", (1_000_000, 768, "euclidean", 32, 200): "C3",
              (10_000_000, 128, "cosine", 16, 100): "C4 (on %d GPU)" % world,
              (5_000_000, 1024, "hamming", 16, 64): "C5 (on %d GPU)" % world}
     cfg_name = known.get((a.n, a.dim, a.metric, a.M, a.ef), "custom")
+    shape = f"{a.n // 1_000_000}M" if a.n % 1_000_000 == 0 and a.n else str(a.n)
     out = {
-        "metric": "vectors indexed/sec (build) + recall@10, 1M x 768 Cosine M=16 efC=100",
+        "metric": f"vectors indexed/sec (build) + recall@10, {shape} x {a.dim} {a.metric.capitalize()} "
+                  f"M={a.M} efC={a.ef}",
         "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / max(1, a.steps), 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -219,17 +267,7 @@ def main():
                    "parallelism": f"item-sharded search x{world}, replicated graph",
                    "distance_order": "x86 (strict)" if a.x86_order else "wave"},
         "roofline": roof,
-        "build": {"n_batches": int(graph.n_batches), "n_distance_evals": int(graph.n_distance_evals),
-                  "evals_walk": int(graph.n_evals_walk), "evals_prune": int(graph.n_evals_prune),
-                  "evals_apply": int(graph.n_evals_apply), "links_added": int(graph.n_links_added),
-                  "t_build_s": round(graph.t_build_s, 3), "t_export_s": round(graph.t_export_s, 3),
-                  "t_upload_s": round(graph.t_upload_s, 3),
-                  "t_walk_kernels_s": round(graph.t_walk_kernels_s, 3),
-                  "t_prune_kernels_s": round(graph.t_prune_kernels_s, 3),
-                  "t_sort_kernels_s": round(graph.t_sort_kernels_s, 3),
-                  "t_apply_kernels_s": round(graph.t_apply_kernels_s, 3),
-                  "tie_pool_overflow": int(graph.n_tie_pool_overflow),
-                  "sub_wave_walks": int(graph.n_sub_walks), "sub_wave_handed_over": int(graph.n_sub_retries)},
+        "build": build_stats(graph),
     }
 
     if rank == 0 and not a.no_recall and a.queries:
@@ -243,7 +281,7 @@ def main():
                          "qps_incl_transfers": round(a.queries / ts, 1)}
         # throughput of the batched searcher on a large query set (same distribution, no ground truth)
         nqs = 32768
-        qb = gen_data(torch, nqs, a.dim, a.data, a.seed + 2000, dev).cpu().numpy()
+        qb = gen_data(torch, nqs, a.dim, a.data, a.seed, dev, queries=True).cpu().numpy()
         qbc, qbh = H.encode_vectors(metric, qb)
         builder.search_knn(qbc[:4096], qbh[:4096], k=10, ef_search=a.ef_search)  # warm-up
         t1 = time.perf_counter()
@@ -255,7 +293,7 @@ def main():
         from oracle import orc
         from tests.conftest import draw_levels
         cores = os.cpu_count() or 1
-        ns = min(a.cpu_sample, a.n)
+        ns = a.n if a.cpu_full else min(a.cpu_sample, a.n)
         if ns <= 0:  # calibrate on 4000 items, then size the sample for ~cpu_seconds of wall time
             nc = min(4000, a.n)
             dsc = orc.Dataset(metric, a.dim, np.arange(nc, dtype=np.uint32), items.codes[:nc],
@@ -273,12 +311,14 @@ def main():
         tc = time.perf_counter() - t1
         out["cpu_baseline"] = {
             "value": round(ns / tc, 1), "unit": "vectors/s", "cores": cores, "kind": "port",
-            "sample": f"first {ns} of the {a.n} vectors, same params, vectors in RAM, "
-                      f"{cores} threads (rayon-like), AVX2+FMA kernels; a smaller index is cheaper "
-                      f"per insert than the 1M one, so this flatters the CPU",
+            "size": "port-full" if ns == a.n else "port-sample",
+            "sample": (f"all {a.n} vectors" if ns == a.n else
+                       f"first {ns} of the {a.n} vectors (a smaller index is cheaper per insert than the "
+                       f"full one, so this flatters the CPU; --cpu-full times all of them)") +
+                      f", same params, vectors in RAM, {cores} threads (rayon-like), AVX2+FMA kernels",
             "seconds": round(tc, 2)}
         full = os.path.join(ROOT, "profiles", "r01_c2_full_scale_recall_parity_final.json")
-        if default_c2 and os.path.exists(full):  # one-off measurement of the same baseline at full size
+        if default_c2 and ns != a.n and os.path.exists(full):  # one-off measurement of the same baseline at full size
             with open(full) as f:
                 fj = json.load(f)
             out["cpu_baseline"]["full_size_run"] = {
@@ -297,6 +337,27 @@ def main():
                                             threads=cores)[0::2], truth_s)
             out["recall_parity_on_sample"] = {"n": ns, "cpu_built": round(r_cpu, 4),
                                               "gpu_built": round(r_gpu, 4)}
+    # ---- a second distribution in the same line: the headline data (well-separated clusters) is the
+    # friendly case for the memory system; `overlap` (overlapping clusters on a 32-d manifold) is what
+    # embedding collections look like.  value_alt / roofline_alt / recall_at_10_alt, same parameters.
+    alt = a.alt_data or ("overlap" if default_c2 else "none")
+    if world == 1 and alt != "none" and alt != a.data:
+        builder.close()
+        del x_dev, x, items
+        xa_dev = gen_data(torch, a.n, a.dim, alt, a.seed, dev)
+        qa_dev = gen_data(torch, a.queries, a.dim, alt, a.seed, dev, queries=True) if a.queries else None
+        items_a = H.ItemSet.from_f32(metric, xa_dev.cpu().numpy())
+        builder, driver, ga, dta = timed_builds(items_a, a.alt_steps, 1)
+        out["value_alt"] = round(a.n * a.alt_steps / dta, 1) if a.alt_steps else 0.0
+        out["alt"] = {"data": f"{alt} synthetic vectors (bench.py gen_data), same n / dim / M / efC",
+                      "steps": a.alt_steps, "ms_per_step": round(1e3 * dta / max(1, a.alt_steps), 2),
+                      "build": build_stats(ga)}
+        out["roofline_alt"] = roofline_of(ga, dta, a.alt_steps)
+        if not a.no_recall and a.queries:
+            truth_a = brute_force_topk(torch, a.metric, xa_dev, qa_dev, 10)
+            qca, qha = H.encode_vectors(metric, qa_dev.cpu().numpy())
+            ida, _, cna = builder.search_knn(qca, qha, k=10, ef_search=a.ef_search)
+            out["recall_at_10_alt"] = round(recall_at_k(ida, cna, truth_a), 4)
     if world > 1:  # replicas must be bit-identical: compare a checksum of the exported graph
         import zlib
         cs = zlib.crc32(graph.nbrs.tobytes()) ^ zlib.crc32(graph.offsets.tobytes())

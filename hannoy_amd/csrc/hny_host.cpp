@@ -1257,7 +1257,10 @@ static int apply_front(hny_builder *b, const void *sel_dev, ApplyArgs &a) {
   a.n_deferred = b->d_nseg.p + 1;
   const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
   prof_begin(b, EV_APPLY);
-  HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream));
+  if (a.deferred && env_int("HNY_APPLY_WAVE", 0) == 0)
+    HIP_TRY(hnyk_apply_append(b->g, a, b->stream)); // appends: one thread per target
+  else
+    HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream)); // one wave per target, prunes included
   prof_end(b);
   b->cur_n_ops = n_ops;
   return HNY_OK;

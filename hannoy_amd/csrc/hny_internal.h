@@ -213,6 +213,8 @@ hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, i
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st);
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st);
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);
+// the segments that cannot overflow, one thread each (a.deferred must be set); the rest -> a.deferred
+hipError_t hnyk_apply_append(const GraphDev &g, const ApplyArgs &a, hipStream_t st);
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st);
 hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,

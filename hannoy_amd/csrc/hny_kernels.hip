@@ -2028,25 +2028,98 @@ __global__ void k_emit(GraphDev g, EmitArgs a) {
   if ((threadIdx.x & 63) == 0 && links) atomicAdd(&g.stats[ST_LINKS], links);
 }
 
-__global__ void k_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg) {
-  const u32 stride = gridDim.x * blockDim.x;
-  const int ln = threadIdx.x & 63;
-  // grid-stride (see k_emit); one slot reservation per wave and step — the order of the segments
-  // in seg_start is free, targets are independent
-  for (u32 b0 = blockIdx.x * blockDim.x; b0 < n_ops; b0 += stride) { // b0: uniform per workgroup
-    const u32 i = b0 + threadIdx.x;
-    bool start = false;
-    if (i < n_ops) {
-      const u64 k = keys[i];
-      start = k != HNY_OP_INVALID && (i == 0 || (keys[i - 1] >> HNY_SEQ_BITS) != (k >> HNY_SEQ_BITS));
+// first op of every (layer, target) segment of the sorted link ops -> seg_start (any order: targets are
+// independent).  1 024 ops per workgroup and step, ONE slot reservation per workgroup and step: with a
+// reservation per wave the 65 k atomics on the one counter were the kernel's whole duration (143 us
+// per 4.2 M ops at C2; 4 k of them: the kernel runs at the speed of its 34 MB read).
+__global__ __launch_bounds__(256) void k_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg) {
+  __shared__ u32 wsum[4];
+  __shared__ u32 base_s;
+  const int tid = threadIdx.x, ln = tid & 63, w = tid >> 6;
+  for (u32 b0 = blockIdx.x * 1024u; b0 < n_ops; b0 += gridDim.x * 1024u) { // b0: uniform per workgroup
+    const u32 i0 = b0 + (u32)tid * 4u;
+    u64 k[5];
+    k[0] = (i0 > 0u && i0 <= n_ops) ? keys[i0 - 1] : HNY_OP_INVALID;
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j + 1] = i0 + (u32)j < n_ops ? keys[i0 + j] : HNY_OP_INVALID;
+    u32 flags = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool start = k[j + 1] != HNY_OP_INVALID &&
+                         ((i0 + (u32)j) == 0u || (k[j] >> HNY_SEQ_BITS) != (k[j + 1] >> HNY_SEQ_BITS));
+      flags |= (start ? 1u : 0u) << j;
     }
-    const u64 mk = __ballot(start);
-    if (!mk) continue;
-    const int leader = __ffsll((long long)mk) - 1;
-    u32 base = 0;
-    if (ln == leader) base = atomicAdd(n_seg, (u32)__popcll(mk));
-    base = (u32)__shfl((int)base, leader, 64);
-    if (start) seg_start[base + (u32)__popcll(mk & ((1ull << ln) - 1ull))] = i;
+    const u32 c = (u32)__popc(flags);
+    u32 incl = c; // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 t = (u32)__shfl_up((int)incl, off, 64);
+      if (ln >= off) incl += t;
+    }
+    if (ln == 63) wsum[w] = incl;
+    __syncthreads();
+    u32 wbase = 0u, total = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j < w) wbase += wsum[j];
+      total += wsum[j];
+    }
+    if (tid == 0) base_s = total ? atomicAdd(n_seg, total) : 0u;
+    __syncthreads();
+    u32 pos = base_s + wbase + incl - c;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if ((flags >> j) & 1u) seg_start[pos++] = i0 + (u32)j;
+    __syncthreads();
+  }
+}
+
+// add_link (hnsw.rs:523-560) for the segments whose list cannot overflow — nearly all of them: one
+// THREAD per (layer, target) appends the segment's links in order (:542-545, no dedup; :530 p == q is
+// a no-op).  A segment that may overflow is left, whole, to k_apply_wg (`deferred`).  The one-wave-
+// per-segment k_apply below spent 295 us per C2 batch walking ~2 M segments of 1-2 ops each.
+__global__ __launch_bounds__(256) void k_apply_append(GraphDev g, ApplyArgs a) {
+  const u32 n_seg = *a.n_seg;
+  for (u32 sg = blockIdx.x * blockDim.x + threadIdx.x; sg < n_seg; sg += gridDim.x * blockDim.x) {
+    const u32 i0 = a.seg_start[sg];
+    const u64 k0 = a.keys[i0] >> HNY_SEQ_BITS;
+    const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
+    u32 cap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)target * g.M0;
+      dist = g.l0_dist + (size_t)target * g.M0;
+      cntp = g.l0_cnt + target;
+    } else { // :534 `layers.get(level)` — the target always has this layer (it was found on it)
+      const size_t u = (size_t)g.upper_idx[target] * g.up_layers + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    const u32 cw = *cntp;
+    if (cw >> 31) continue; // frozen: full and self-pruned to full, nothing can change it (see k_apply)
+    u32 cnt = cw & 0xFFFFu;
+    u32 nops = 0;
+    for (u32 i = i0; i < a.n_ops; i++) {
+      const u64 key = a.keys[i];
+      if (key == HNY_OP_INVALID || (key >> HNY_SEQ_BITS) != k0) break;
+      nops++;
+      if (cnt + nops > cap) break;
+    }
+    if (cnt + nops > cap) { // may overflow: k_apply_wg replays the whole segment
+      a.deferred[atomicAdd(a.n_deferred, 1u)] = i0;
+      continue;
+    }
+    for (u32 i = i0; i < i0 + nops; i++) {
+      const u64 val = a.vals[i];
+      if ((u32)(val & 0xFFFFFFFFull) == target) continue; // :530 p == q.1
+      ids[cnt] = (u32)(val & 0xFFFFFFFFull);
+      dist[cnt] = __uint_as_float((u32)(val >> 32));
+      cnt++;
+    }
+    *cntp = cnt;
   }
 }
 
@@ -2825,8 +2898,13 @@ hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st) {
 }
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st) {
   if (!n_ops) return hipSuccess;
-  hipLaunchKernelGGL(k_segments, dim3(std::min<u32>((n_ops + 255) / 256, 2048u)), dim3(256), 0, st, keys,
+  hipLaunchKernelGGL(k_segments, dim3(std::min<u32>((n_ops + 1023) / 1024, 2048u)), dim3(256), 0, st, keys,
                      n_ops, seg_start, n_seg);
+  return hipGetLastError();
+}
+hipError_t hnyk_apply_append(const GraphDev &g, const ApplyArgs &a, hipStream_t st) {
+  if (!a.n_ops) return hipSuccess;
+  hipLaunchKernelGGL(k_apply_append, dim3(std::min<u32>((a.n_ops / 2 + 255) / 256, 4096u)), dim3(256), 0, st, g, a);
   return hipGetLastError();
 }
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st) {
