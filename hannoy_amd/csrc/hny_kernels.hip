@@ -267,6 +267,13 @@ struct RowsInFlight {
   // 16-byte loads in flight per lane ~ 12..16
   static constexpr int U = NCH >= 12 ? 1 : (NCH >= 6 ? 2 : (NCH >= 3 ? 4 : (NCH == 2 ? 6 : 8)));
 };
+// dist_rows: load groups per pass.  A pass covers (64 / LPR) * U rows and the build never has more
+// than max(M, M0) <= 64 new rows at once — typically ~11 — while every group of a pass costs
+// instructions even when it is skipped: short rows take 4 groups (LPR 8: 32 rows per pass).
+template <int LPR, int NCH>
+struct DistGroups {
+  static constexpr int U = (NCH == 1 && LPR <= 16) ? 4 : RowsInFlight<NCH>::U;
+};
 
 // Strict mode: the f32 distances exactly as the reference computes them on an x86_64 host with
 // AVX+FMA (dispatch simple.rs:19-47,53-79): dim >= 32 -> 32 fma partials, element i -> partial
@@ -385,19 +392,24 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
     return;
   }
   constexpr int RPG = 64 / LPR;               // rows per wave-wide load instruction
-  constexpr int U = RowsInFlight<NCH>::U;     // load groups in flight
+  constexpr int U = DistGroups<LPR, NCH>::U;  // load groups in flight
   constexpr int RPI = RPG * U;
   const int ln = threadIdx.x, t = ln % LPR, sub = ln / LPR;
   for (int k0 = 0; k0 < n; k0 += RPI) {
     float4 r[U][NCH];
     float rn[U];
+    u32 rids[U]; // every group's row id first: the LDS reads go out back to back, not one per branch
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int ri = k0 + u * RPG + sub;
+      if (ri > n - 1) ri = n - 1;
+      rids[u] = ids[ri];
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       rn[u] = 0.f;
       if (k0 + u * RPG < n) { // wave-uniform
-        int ri = k0 + u * RPG + sub;
-        if (ri > n - 1) ri = n - 1;
-        u32 rid = ids[ri];
+        u32 rid = rids[u];
         if (LPR == 64) rid = __builtin_amdgcn_readfirstlane(rid);
         const unsigned char *p = g.rows + (size_t)rid * g.row_stride;
         load_row<LPR, NCH>(p, t, g.n16, r[u]);
@@ -1126,6 +1138,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   BeamR<RCN> rb;
 #pragma unroll
   for (int c = 0; c < RCN; c++) rb.r[c] = 0ull;
+  if constexpr (RB) s.rcap = s.rcap < 64 * RCN ? s.rcap : 64 * RCN; // what the register beam can hold
   Visited vis;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u), a.vis_slots);
@@ -1694,7 +1707,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_linear(GraphDev g, NnsArgs a) {
 template <int LPR, int NCH>
 __device__ int wave_prune(const GraphDev &g, const u64 *list, int n, int cap, u64 *S, u32 *s_ids,
                           float *tmp_d, u64 &evals) {
-  constexpr int RPI = (64 / LPR) * RowsInFlight<NCH>::U;
+  constexpr int RPI = (64 / LPR) * DistGroups<LPR, NCH>::U;
   const int ln = threadIdx.x, t = ln % LPR;
   int s_len = 0;
   for (int ci = 0; ci < n; ci++) {
@@ -2659,6 +2672,9 @@ struct Hot {
         if constexpr (C <= HNY_RB_MAX_NCH) { // beam in registers (res <= 128 entries)
           const char *e = getenv("HNY_NO_RB"); // read per launch: tests flip it inside one process
           if (a.rcap <= 128 && !(e && atoi(e) != 0)) {
+            // (a ONE-chunk register beam for ef <= 64 — every beam scan a single ballot — was measured on
+            // C5: walk 0.692 s against 0.668 s with two chunks, i.e. no gain; the beam scans are not what
+            // bounds the short-row walk)
             if (a.reader_mode)
               hipLaunchKernelGGL((k_walk<L, C, false, SP, true, 2>), dim3(grid), dim3(64), lds, st, g, a);
             else

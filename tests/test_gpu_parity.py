@@ -1043,3 +1043,18 @@ def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
     og2 = orc.build_incremental(ds2, og, to_insert, lv, to_delete, **kw_o)
     gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, devices=[0, 0], **kw_g)
     _same_graph(gg2, og2)
+
+
+def test_m0_beyond_64_is_refused_loudly(hny):
+    """include/hannoy_amd.h: max(M, M0) <= 64 (one lane per neighbour slot).  The reference's fuzz
+    configuration M = 16, M0 = 768 (src/tests/fuzz.rs:86-87) is out of contract: the build must fail
+    with HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp), while (32, 64), the
+    largest pair of the reference's Python API (python.rs:280), builds."""
+    v = np.random.default_rng(1).uniform(-1, 1, (500, 32)).astype(np.float32)
+    items = hny.ItemSet.from_f32(hny.COSINE, v)
+    for M, M0 in ((16, 768), (16, 96), (65, 65)):
+        with pytest.raises(hny.HannoyError) as e:
+            hny.build(items, M=M, M0=M0, ef_construction=32)
+        assert e.value.code == -5
+    g = hny.build(items, M=32, M0=64, ef_construction=32)
+    assert len(g.rec_item) >= 500
