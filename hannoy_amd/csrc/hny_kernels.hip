@@ -471,6 +471,94 @@ __device__ __forceinline__ void dist_rows(const GraphDev &g, const float4 (&q)[N
   }
 }
 
+// The wave order of a 16- or 32-lane row group, computed by EIGHT lanes per row (k_walk, rows of
+// 9..32 sixteen-byte units: 128-d f32, 129..512-B codes).  One wave-wide load then covers 8 rows
+// instead of 4 or 2, and the per-group instructions (row id, address, exec mask, shuffles,
+// finaliser) are paid once per 8 rows: ~90 instead of ~220 VALU instructions for the ~11 new rows of
+// an expansion at 128-d.  Bit-identical by construction: lane t holds units t, t + 8 (, t + 16,
+// t + 24), runs the same 4-element chain per unit and adds the per-unit partials in the order of the
+// xor butterfly's first steps — off = 16: p[t] + p[t ^ 16], off = 8: that + its partner — before
+// the butterfly continues across the 8 lanes with off = 4, 2, 1.
+template <int LPRO>
+__device__ __forceinline__ void dist_rows_narrow(const GraphDev &g, const float4 (&q)[LPRO / 8], float qn,
+                                                 const u32 *ids, int n, float *out) {
+  static_assert(LPRO == 16 || LPRO == 32, "8 lanes stand in for 16 or 32");
+  constexpr int NQ = LPRO / 8, U = 2;
+  const int ln = threadIdx.x, t = ln & 7, sub = ln >> 3;
+  const int j2 = fold2_row<8>();
+  for (int k0 = 0; k0 < n; k0 += 8 * U) {
+    float4 r[U][NQ];
+    float rn[U];
+    u32 rids[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int ri = k0 + u * 8 + sub;
+      if (ri > n - 1) ri = n - 1;
+      rids[u] = ids[ri];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      rn[u] = 0.f;
+      if (k0 + u * 8 < n) { // wave-uniform
+        const unsigned char *p = g.rows + (size_t)rids[u] * g.row_stride;
+#pragma unroll
+        for (int c = 0; c < NQ; c++) {
+          const u32 f = (u32)(c * 8 + t);
+          r[u][c] = f < g.n16 ? *reinterpret_cast<const float4 *>(p + (size_t)f * 16)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (g.norms) rn[u] = g.norms[rids[u]];
+      } else {
+#pragma unroll
+        for (int c = 0; c < NQ; c++) r[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const bool two = k0 + 8 < n; // wave-uniform: the second group holds rows
+    float d;
+    int j;
+    if (g.mclass == MC_BIN) {
+      u32 pc[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) pc[u] = partial_bin<NQ>(q, r[u]);
+      u32 y;
+      if (two) {
+        y = fold2<8, u32>(pc[0], pc[1]);
+        j = j2;
+      } else {
+        y = butterfly_u32<8>(pc[0]);
+        j = 0;
+      }
+      d = finalize_bin(g, y, qn, j ? rn[1] : rn[0]);
+    } else {
+      float pa[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float pu[NQ];
+#pragma unroll
+        for (int c = 0; c < NQ; c++) {
+          const float4 qc[1] = {q[c]}, rc[1] = {r[u][c]};
+          pu[c] = partial_f32<1>(g.mclass, qc, rc);
+        }
+        if constexpr (NQ == 4)
+          pa[u] = (pu[0] + pu[2]) + (pu[1] + pu[3]); // off = 16, then off = 8
+        else
+          pa[u] = pu[0] + pu[1];                     // off = 8
+      }
+      float y;
+      if (two) {
+        y = fold2<8, float>(pa[0], pa[1]);
+        j = j2;
+      } else {
+        y = butterfly_f32<8>(pa[0]);
+        j = 0;
+      }
+      d = finalize_f32(g, y, qn, j ? rn[1] : rn[0]);
+    }
+    const int ri = k0 + j * 8 + sub;
+    if ((two ? (t & 3) == 0 : t == 0) && ri < n) out[ri] = d;
+  }
+}
+
 // neighbour list of (layer, node): ids in insertion order, HNY_SENT beyond the count
 // (get_neighbours, hnsw.rs:428-456, fresh DB: in-memory lists only)
 __device__ __forceinline__ const u32 *nbr_ids(const GraphDev &g, u32 layer, u32 node, u32 &cap) {
@@ -878,8 +966,9 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 }
 
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
-template <int LPR, int NCH, bool BIG_EPS, int RC = 0> // RC: 64-entry chunks of a register beam, 0 = LDS beam
-__device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer,
+// QN != NCH: the query is held 8 lanes per row (dist_rows_narrow)
+template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH> // RC: 64-entry chunks of a register beam, 0 = LDS beam
+__device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[QN], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
                                const unsigned char *qrow, BeamR<(RC ? RC : 1)> &rb) {
@@ -906,7 +995,8 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     if (BIG_EPS) WSYNC();
     if (ln < ne) nb_ids[ln] = id;
     WSYNC();
-    dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
+    if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, ne, nb_d);
+    else dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
     evals += (u64)ne;
     WSYNC();
     for (int r = 0; r < ne; r++) {
@@ -1064,7 +1154,8 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
       if (isnew) nb_ids[rank] = id;
       WSYNC();
-      dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow); // :503
+      if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, n_new, nb_d); // :503
+      else dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow);
       evals += (u64)n_new;
       WSYNC();
       const float myd = ln < n_new ? nb_d[ln] : 0.f;
@@ -1111,6 +1202,9 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   constexpr bool RB = RC != 0;
   constexpr int RCN = RC ? RC : 1;
   static_assert(!(RB && (BIG_EPS || SP == 0)), "register beam: specialised kernels only");
+  // rows of 9..32 units in the specialised kernels: 8 lanes per row (dist_rows_narrow)
+  constexpr bool NARROW = SP != 0 && NCH == 1 && (LPR == 16 || LPR == 32);
+  constexpr int QN = NARROW ? LPR / 8 : NCH;
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
@@ -1140,6 +1234,9 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   for (int c = 0; c < RCN; c++) rb.r[c] = 0ull;
   if constexpr (RB) s.rcap = s.rcap < 64 * RCN ? s.rcap : 64 * RCN; // what the register beam can hold
   Visited vis;
+  // (for short rows, which have no LDS table, the same table in GLOBAL memory — L2 / Infinity-Cache
+  // resident, 16-32 KB per wave — in front of the bitset was measured too: C5 walk 0.71 s against
+  // 0.69-0.75, C4-like 0.88 against 0.88: no gain, DESIGN.md §5 "Short rows")
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u), a.vis_slots);
   u64 evals = 0;
@@ -1162,8 +1259,16 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       qrow = g.rows + (size_t)qslot * g.row_stride;
       if (g.norms) qn = g.norms[qslot];
     }
-    float4 q[NCH];
-    load_row<LPR, NCH>(qrow, t, g.n16, q);
+    float4 q[QN];
+    if constexpr (NARROW) {
+#pragma unroll
+      for (int c = 0; c < QN; c++) {
+        const u32 f = (u32)(c * 8 + (ln & 7));
+        q[c] = f < g.n16 ? *reinterpret_cast<const float4 *>(qrow + (size_t)f * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      load_row<LPR, NCH>(qrow, t, g.n16, q);
+    }
 
     int n_eps;
     u32 start_layer;
@@ -1191,7 +1296,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH, BIG_EPS, RC>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+      walk_one_layer<LPR, NCH, BIG_EPS, RC, QN>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                    nb_d, evals, err_iter, qrow, rb);
       if (last) break;
       // :305-306 eps = [closest]
@@ -1258,7 +1363,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS, RC>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 out=gpurun_out/r2_pmc
 rm -rf $out && mkdir -p $out
-ARGS="--no-cpu --no-recall --queries 0 --steps 1 --warmup 0 --items 5000000 --dim 1024 --metric hamming --ef 64"
+ARGS=${ARGS:-"--no-cpu --no-recall --queries 0 --steps 1 --warmup 0 --alt-data none --items 5000000 --dim 1024 --metric hamming --ef 64"}
 run() { # name
   local name=$1
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${name}_f -- python3 bench.py $ARGS > $out/${name}_f.log 2>&1
@@ -12,5 +12,5 @@ run() { # name
   find $out -name "*.csv" -delete
   echo "== $name"; cat $out/$name.txt
 }
-HNY_SUB=0 run c5_classic
-HNY_SUB=1 run c5_sub
+HNY_SUB=0 run ${NAME:-c5}_classic
+[ -n "$ONLY_CLASSIC" ] || HNY_SUB=1 run ${NAME:-c5}_sub
