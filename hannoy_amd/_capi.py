@@ -36,10 +36,14 @@ ERR_IO = -9
 NNS_NONE = 0xFFFFFFFF  # by_item: the reference returns None
 
 
+CANCEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
 class QueryOpts(C.Structure):
     _fields_ = [("k", C.c_uint32), ("ef_search", C.c_uint32), ("has_candidates", C.c_int32),
                 ("candidates", C.c_void_p), ("n_candidates", C.c_uint64), ("linear_below", C.c_uint32),
-                ("linear_below_ratio", C.c_float)]
+                ("linear_below_ratio", C.c_float), ("cancel", CANCEL_FN), ("cancel_ctx", C.c_void_p),
+                ("did_cancel", C.POINTER(C.c_int32))]
 
 
 class HannoyError(RuntimeError):
@@ -52,7 +56,6 @@ class BuildCancelled(HannoyError):
     """Error::BuildCancelled (/root/reference/src/error.rs:58-59)"""
 
 
-CANCEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 KV_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8),
                       C.c_size_t)
@@ -666,11 +669,18 @@ class Builder:
         return ids, dists, counts
 
     def nns(self, qcodes=None, qheaders=None, k=10, ef_search=100, candidates=None, query_items=None,
-            linear_below=1000, linear_below_ratio=1.0):
+            linear_below=1000, linear_below_ratio=1.0, cancel=None):
         """Reader::nns(k).ef_search(..).candidates(..).linear_below(..).by_vector / .by_item
-        (/root/reference/src/reader.rs:60-262).  counts == NNS_NONE where by_item returns None."""
+        (/root/reference/src/reader.rs:60-262).  counts == NNS_NONE where by_item returns None.
+        cancel: the closure of the *_with_cancellation variants; self.did_cancel tells whether it fired."""
         qo = QueryOpts()
         qo.k, qo.ef_search = k, ef_search
+        flag = C.c_int32(0)
+        if cancel is not None:
+            fn = CANCEL_FN(lambda _ctx: 1 if cancel() else 0)
+            qo.cancel = fn
+            qo.did_cancel = C.pointer(flag)
+        self._cancel_flag = flag
         cand = None
         if candidates is not None:
             cand = np.ascontiguousarray(candidates, np.uint32)
@@ -688,4 +698,5 @@ class Builder:
         counts = np.zeros(nq, np.uint32)
         _check(load_library().hny_builder_nns(self._h, C.byref(qo), nq, qc, qs, qh, qi, _p(ids), _p(dists),
                                               _p(counts)))
+        self.did_cancel = bool(flag.value)
         return ids, dists, counts

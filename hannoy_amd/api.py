@@ -414,9 +414,9 @@ class Searched:
 
 
 class QueryBuilder:
-    """reader.rs:60-262.  A batch runs to completion on the GPU, so the *_with_cancellation variants
-    poll `cancel_fn` once, before the launch (a cancelled search returns what was found so far:
-    nothing)."""
+    """reader.rs:60-262.  The *_with_cancellation variants hand `cancel_fn` to hny_builder_nns, which
+    polls it while the batch runs and stops taking queries once it fires (hny_query_opts.cancel): a
+    cancelled search returns what was found so far."""
 
     def __init__(self, reader, count):
         self.reader, self.count = reader, int(count)
@@ -444,18 +444,18 @@ class QueryBuilder:
         return dict(k=self.count, ef_search=self._ef, candidates=self._candidates,
                     linear_below=self._linear_below, linear_below_ratio=self._ratio)
 
-    def by_vectors(self, vectors):
+    def by_vectors(self, vectors, cancel=None):
         """batched by_vector: (ids [nq, count], distances, counts)"""
         r = self.reader
         q = np.ascontiguousarray(vectors, np.float32)
         if q.ndim != 2 or q.shape[1] != r.dimensions:
             raise InvalidVecDimension(f"expected {r.dimensions}, received {q.shape[-1]}")
         qc, qh = capi.encode_vectors(r.db.distance.value, q)
-        return r._b.nns(qc, qh, **self._kw())
+        return r._b.nns(qc, qh, cancel=cancel, **self._kw())
 
-    def by_items(self, items):
+    def by_items(self, items, cancel=None):
         """batched by_item; counts == capi.NNS_NONE where the reference returns None"""
-        return self.reader._b.nns(query_items=np.ascontiguousarray(items, np.uint32), **self._kw())
+        return self.reader._b.nns(query_items=np.ascontiguousarray(items, np.uint32), cancel=cancel, **self._kw())
 
     def by_vector(self, vector):
         """reader.rs:132-148"""
@@ -466,10 +466,9 @@ class QueryBuilder:
         q = np.asarray(vector, np.float32)
         if q.ndim != 1 or len(q) != self.reader.dimensions:
             raise InvalidVecDimension(f"expected {self.reader.dimensions}, received {q.size}")
-        if cancel_fn():
-            return Searched([], True)
-        ids, dists, counts = self.by_vectors(q[None, :])
-        return Searched([(int(ids[0, j]), float(dists[0, j])) for j in range(counts[0])])
+        ids, dists, counts = self.by_vectors(q[None, :], cancel=cancel_fn)
+        return Searched([(int(ids[0, j]), float(dists[0, j])) for j in range(counts[0])],
+                        self.reader._b.did_cancel)
 
     def by_item(self, item):
         """reader.rs:81-90"""
@@ -477,14 +476,11 @@ class QueryBuilder:
 
     def by_item_with_cancellation(self, item, cancel_fn):
         """reader.rs:108-119"""
-        if cancel_fn():
-            if not self.reader.contains_item(item):
-                return None
-            return Searched([], True)
-        ids, dists, counts = self.by_items([item])
+        ids, dists, counts = self.by_items([item], cancel=cancel_fn)
         if counts[0] == capi.NNS_NONE:
             return None
-        return Searched([(int(ids[0, j]), float(dists[0, j])) for j in range(counts[0])])
+        return Searched([(int(ids[0, j]), float(dists[0, j])) for j in range(counts[0])],
+                        self.reader._b.did_cancel)
 
 
 class Reader:

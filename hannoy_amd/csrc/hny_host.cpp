@@ -1658,11 +1658,67 @@ int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot
   return HNY_OK;
 }
 
+// The cancel closure of the *_with_cancellation searches (reader.rs:108-119, 167-186; probe :333): a
+// pinned, device-visible word the kernels' work-queue loops poll, raised by the calling thread, which
+// probes the closure while it waits for the stream.
+struct SearchCancel {
+  int (*fn)(void *) = nullptr;
+  void *ctx = nullptr;
+  u32 *h = nullptr, *d = nullptr;
+  bool cancelled = false;
+  ~SearchCancel() {
+    if (h) (void)hipHostFree(h);
+  }
+  hipError_t init(const hny_query_opts *qo) {
+    if (!qo || !qo->cancel) return hipSuccess;
+    fn = qo->cancel;
+    ctx = qo->cancel_ctx;
+    hipError_t e = hipHostMalloc((void **)&h, 64, hipHostMallocMapped);
+    if (e != hipSuccess) return e;
+    *h = 0u;
+    return hipHostGetDevicePointer((void **)&d, h, 0);
+  }
+  bool probe() { // before a chunk is started
+    if (fn && !cancelled && fn(ctx)) {
+      cancelled = true;
+      __atomic_store_n(h, 1u, __ATOMIC_RELEASE);
+    }
+    return cancelled;
+  }
+  hipError_t wait(hny_builder *b) {
+    if (!fn) return hipStreamSynchronize(b->stream);
+    hipEvent_t ev;
+    hipError_t e = next_sync_event(b, &ev);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(ev, b->stream);
+    if (e != hipSuccess) return e;
+    for (;;) {
+      e = hipEventQuery(ev);
+      if (e != hipErrorNotReady) return e;
+      (void)probe();
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+};
+
+static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, size_t qstride,
+                           const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
+                           float *out_dists, uint32_t *out_counts, const hny_query_opts *qo);
+
 int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, size_t qstride,
                            const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
                            float *out_dists, uint32_t *out_counts) {
+  return search_knn_impl(b, nq, qvectors, qstride, qheaders, k, ef_search, out_ids, out_dists, out_counts, nullptr);
+}
+
+static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, size_t qstride,
+                           const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
+                           float *out_dists, uint32_t *out_counts, const hny_query_opts *qo) {
   if (!b || !qvectors || !qheaders || !out_ids || !out_dists || !out_counts || k == 0)
     return fail(HNY_ERR_INVALID_ARG, "bad argument");
+  SearchCancel sc;
+  if (qo && qo->did_cancel) *qo->did_cancel = 0;
+  HIP_TRY(sc.init(qo));
   if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   const uint32_t ef = std::max(ef_search, k); // reader.rs:746
   if (ef + 1 > b->rcap && ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
@@ -1699,6 +1755,10 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
   u32 *queues = b->d_nseg.p + 4;
   for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
     uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+    if (sc.probe()) { // cancelled: nothing of this chunk is started
+      for (uint32_t i = 0; i < cnt; i++) out_counts[q0 + i] = 0u;
+      continue;
+    }
     int rc = upload_rows((const unsigned char *)qvectors + q0 * qstride, qstride, vb, cnt,
                          b->g.row_stride, dq.p, b->stream);
     if (rc) return rc;
@@ -1730,6 +1790,8 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.vis_slots = vis_slots_for(b, w.rcap);
     w.eps_cap = eps_cap_of(b);
     w.queue = queues;
+    w.cancel = sc.d;
+    if (sc.d) HIP_TRY(hnyk_fill_u32(dcn.p, 0xFFFFFFFFu, cnt, b->stream)); // = never finished
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
     if (b->locality && b->max_level >= 1 && cnt >= 2048) {
@@ -1754,8 +1816,12 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
     HIP_TRY(hnyk_take_topk(dcand.p, dcn.p, rcap, k, cnt, dtop.p, b->stream));
     HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(sc.wait(b));
     for (uint32_t i = 0; i < cnt; i++) { // drain_asc().take(k), reader.rs:797-798
+      if (sc.d && hn[i] == 0xFFFFFFFFu) { // the batch was cancelled before this query finished
+        out_counts[q0 + i] = 0u;
+        continue;
+      }
       uint32_t c = std::min<uint32_t>(k, hn[i]);
       for (uint32_t j = 0; j < c; j++) {
         u64 e = hc[(size_t)i * k + j];
@@ -1766,6 +1832,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, si
       out_counts[q0 + i] = c;
     }
   }
+  if (sc.cancelled && qo && qo->did_cancel) *qo->did_cancel = 1;
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
   if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER]) {
@@ -1789,8 +1856,8 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
   if (!(qo->linear_below_ratio >= 0.f && qo->linear_below_ratio <= 1.f)) // reader.rs:253-256
     return fail(HNY_ERR_INVALID_ARG, "linear scan threshold ratio must be between 0.0 and 1.0");
   if (!qo->has_candidates && !by_item)
-    return hny_builder_search_knn(b, nq, qvectors, qstride, qheaders, qo->k, qo->ef_search, out_ids,
-                                  out_dists, out_counts);
+    return search_knn_impl(b, nq, qvectors, qstride, qheaders, qo->k, qo->ef_search, out_ids, out_dists,
+                           out_counts, qo);
   if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   const uint32_t k = qo->k, ef = std::max(qo->ef_search, k); // reader.rs:746, 837
   if (ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
@@ -1877,8 +1944,16 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
   std::vector<u32> qs(chunk), members(chunk), hn(chunk), hst(chunk);
   std::vector<u64> hc((size_t)chunk * k);
   u32 *queues = b->d_nseg.p + 4;
+  SearchCancel sc; // hny_query_opts.cancel
+  if (qo->did_cancel) *qo->did_cancel = 0;
+  HIP_TRY(sc.init(qo));
   for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+    if (sc.probe()) { // nothing of this chunk is started: 0 hits each (unknown items stay None)
+      for (uint32_t i = 0; i < cnt; i++)
+        out_counts[q0 + i] = by_item && slot_of(query_items[q0 + i]) < 0 ? NONE : 0u;
+      continue;
+    }
     uint32_t n_mem = 0;
     if (by_item) {
       for (uint32_t i = 0; i < cnt; i++) {
@@ -1929,6 +2004,8 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     a.status = dstatus.p;
     a.cand_slots = dcslots.p;
     a.n_cand_slots = (u32)cand_slots.size();
+    a.cancel = sc.d;
+    if (sc.d) HIP_TRY(hnyk_fill_u32(dstatus.p, 2u, cnt, b->stream)); // 2 = never started
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     if (linear) {
       HIP_TRY(hnyk_nns_linear(b->g, a, b->shape, (int)std::min<uint32_t>(n_mem, b->walk_slots), b->stream));
@@ -1937,10 +2014,10 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
       a.heap_cap = heap_small;
       HIP_TRY(hnyk_nns_filtered(b->g, a, b->shape, (int)std::min<uint32_t>(n_mem, grid_small), b->stream));
       HIP_TRY(hipMemcpyAsync(hst.data(), dstatus.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
-      HIP_TRY(hipStreamSynchronize(b->stream));
+      HIP_TRY(sc.wait(b));
       uint32_t n_retry = 0;
       for (uint32_t j = 0; j < n_mem; j++)
-        if (hst[members[j]]) members[n_retry++] = members[j];
+        if (hst[members[j]] == 1u) members[n_retry++] = members[j];
       if (n_retry && heap_small < heap_full) {
         if (!grid_full) {
           grid_full = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b->walk_slots, (2ull << 30) / ((uint64_t)heap_full * 8)));
@@ -1960,9 +2037,13 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(hst.data(), dstatus.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(sc.wait(b));
     for (uint32_t i = 0; i < cnt; i++) {
       if (by_item && out_counts[q0 + i] == NONE && slot_of(query_items[q0 + i]) < 0) continue;
+      if (hst[i] == 2u || (sc.cancelled && hst[i] == 1u)) { // cancelled before this query (re)started
+        out_counts[q0 + i] = 0u;
+        continue;
+      }
       if (hst[i]) return fail(HNY_ERR_DEVICE, "search queue overflow");
       uint32_t c = std::min<uint32_t>(k, hn[i]);
       for (uint32_t j = 0; j < c; j++) {
@@ -1974,6 +2055,7 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
       out_counts[q0 + i] = c;
     }
   }
+  if (sc.cancelled && qo->did_cancel) *qo->did_cancel = 1;
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
   if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER]) {

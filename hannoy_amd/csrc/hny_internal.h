@@ -121,6 +121,7 @@ struct WalkArgs {
   u32 force_retry;  // test hook: hand over every member with m % force_retry == 0
   u32 *n_retry;
   const u32 *hi_dev; // k_walk: hi = lo + *hi_dev (null: hi as given)
+  const u32 *cancel; // reader mode: pinned host word, non-zero = take no further query (reader.rs:333)
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -154,6 +155,9 @@ struct NnsArgs {
   // brute_force_search (reader.rs:667-711): the existing candidates, ascending
   const u32 *cand_slots;
   u32 n_cand_slots;
+  // cancellation (reader.rs:333): a host word (pinned, mapped) the work-queue loop polls; non-zero =
+  // take no further query.  status[] == 2 marks the queries that were never started.
+  const u32 *cancel;
 };
 
 struct PruneArgs {

@@ -1245,7 +1245,11 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   // dynamic work queue: queries differ a lot in length, a static stride leaves a long launch tail
   for (;;) {
     u32 m = 0;
-    if (ln == 0) m = a.lo + atomicAdd(a.queue, 1u);
+    if (ln == 0) {
+      m = a.lo + atomicAdd(a.queue, 1u);
+      if constexpr (RM || SP == 0) // the Visitor's cancel probe (reader.rs:333), between queries
+        if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) m = 0xFFFFFFFFu;
+    }
     m = uni(m);
     if (m >= a.hi) break;
     if (a.perm) m = uni((u32)a.perm[m - a.lo]); // locality order; results stay indexed by member
@@ -1622,7 +1626,11 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
 
   for (;;) {
     u32 mi = 0;
-    if (ln == 0) mi = atomicAdd(a.queue, 1u);
+    if (ln == 0) {
+      mi = atomicAdd(a.queue, 1u);
+      // the Visitor's cancel probe (reader.rs:333), between queries: a cancelled batch starts no more
+      if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) mi = 0xFFFFFFFFu;
+    }
     mi = uni(mi);
     if (mi >= a.n_members) break;
     const u32 m = a.members ? uni(a.members[mi]) : mi;
@@ -1755,7 +1763,10 @@ __global__ __launch_bounds__(64, 4) void k_nns_linear(GraphDev g, NnsArgs a) {
   u32 res_err = 0;
   for (;;) {
     u32 mi = 0;
-    if (ln == 0) mi = atomicAdd(a.queue, 1u);
+    if (ln == 0) {
+      mi = atomicAdd(a.queue, 1u);
+      if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) mi = 0xFFFFFFFFu;
+    }
     mi = uni(mi);
     if (mi >= a.n_members) break;
     const u32 m = a.members ? uni(a.members[mi]) : mi;

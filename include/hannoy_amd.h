@@ -231,8 +231,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvect
  * runs with the filter applied to the result heap only (Visitor::visit :301-369), then the
  * exhaustive fallback (:771-795 / :864-890).  query_items != NULL = by_item: one item id per query
  * instead of qvectors/qheaders (which may then be NULL); out_counts[i] = HNY_NNS_NONE where the
- * reference returns None (unknown item, or nothing can ever match, :822-826).  The cancel closure of
- * the *_with_cancellation variants has no counterpart: a batch runs to completion. */
+ * reference returns None (unknown item, or nothing can ever match, :822-826). */
 #define HNY_NNS_NONE 0xFFFFFFFFu
 typedef struct {
   uint32_t k;                 /* Reader::nns(count) */
@@ -242,6 +241,14 @@ typedef struct {
   uint64_t n_candidates;
   uint32_t linear_below;      /* default 1000 (reader.rs:28) */
   float linear_below_ratio;   /* default 1.0 (reader.rs:31); must be in [0, 1] (:253-256) */
+  /* by_vector_with_cancellation / by_item_with_cancellation (reader.rs:108-119, 167-186; the probe
+   * sits in Visitor::visit, :333): `cancel` is polled by the calling thread while the batch runs
+   * (every ~0.2 ms); once it returns non-zero the kernels stop taking queries from the work queue.
+   * Queries already finished keep their results, the others report 0 hits (Searched { nns: what was
+   * found so far, did_cancel: true }), and *did_cancel (if given) is set to 1.  NULL = no probe. */
+  int (*cancel)(void *);
+  void *cancel_ctx;
+  int32_t *did_cancel;
 } hny_query_opts;
 int hny_builder_nns(hny_builder *b, const hny_query_opts *opts, uint64_t n_queries, const void *qvectors,
                     size_t qstride, const void *qheaders, const uint32_t *query_items, uint32_t *out_ids,

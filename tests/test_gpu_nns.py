@@ -171,3 +171,44 @@ def test_loaded_graph_search_equals_oracle(orc, hny):
     want = orc.search(ds, stored, None, None, k=10, ef_search=40, order=orc.ORDER_WAVE, threads=8, query_items=qi)
     _same(got, want)
     r.close()
+
+
+def test_search_cancellation_through_the_c_abi(orc, hny):
+    """by_vector_with_cancellation / by_item_with_cancellation (reader.rs:108-119, 167-186; probe at
+    :333; src/tests/reader.rs:145-170): hny_query_opts.cancel is polled while the batch runs.  A
+    closure that never fires changes nothing; one that fires at once starts no query (0 hits each,
+    unknown items stay None, did_cancel set); one that fires in the middle of a large batch leaves
+    the finished queries' results exactly as an uncancelled search returns them."""
+    rng = np.random.default_rng(12)
+    n, dim = 20000, 64
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    qs = rng.uniform(-1, 1, (30000, dim)).astype(np.float32)
+    ds = orc.Dataset.from_f32(orc.EUCLIDEAN, vecs, draw_levels(n, 16, seed=3))
+    items = hny.ItemSet(hny.EUCLIDEAN, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    qc = orc.encode_vectors(orc.EUCLIDEAN, qs)
+    qh = orc.make_headers(orc.EUCLIDEAN, dim, qc)
+    with hny.Builder(items, M=16, M0=32, ef_construction=64) as b:
+        b.run()
+        b.finish()
+        ref = b.nns(qc, qh, k=10, ef_search=64)
+        assert not b.did_cancel
+        same = b.nns(qc, qh, k=10, ef_search=64, cancel=lambda: False)
+        assert not b.did_cancel
+        for x, y in zip(ref, same):
+            assert np.array_equal(x, y)
+        ids, dists, counts = b.nns(qc, qh, k=10, ef_search=64, cancel=lambda: True)
+        assert b.did_cancel and not counts.any()
+        ids, dists, counts = b.nns(query_items=np.array([5, 2 ** 31, 7], np.uint32), k=5, cancel=lambda: True)
+        assert b.did_cancel and counts.tolist() == [0, hny.NNS_NONE, 0]
+        calls = []
+
+        def later():  # fires on the third probe: the batch is under way by then
+            calls.append(1)
+            return len(calls) >= 3
+        ids, dists, counts = b.nns(qc, qh, k=10, ef_search=64, cancel=later)
+        done = counts > 0
+        if b.did_cancel:  # (a very fast batch may finish before the third probe)
+            assert np.array_equal(ids[done], ref[0][done]) and np.array_equal(counts[done], ref[2][done])
+            assert np.array_equal(dists[done].view(np.uint32), ref[1][done].view(np.uint32))
+        else:
+            assert done.all()
