@@ -238,6 +238,10 @@ struct hny_builder {
   uint64_t n_done0 = 0;
   uint32_t up_layers = 1;
   std::vector<uint32_t> entry_points; // slots ascending
+  // export: which (item, layer) records exist is fixed for the builder's life (finish() reuses it)
+  std::vector<uint64_t> rec_first;
+  std::vector<uint32_t> rec_item_t;
+  std::vector<uint8_t> rec_layer_t;
   std::vector<int32_t> upper_idx;
   uint32_t max_level = 0, n_upper = 0;
   LaunchShape shape{64, 1};
@@ -312,10 +316,12 @@ static uint32_t eps_cap_of(const hny_builder *b) {
   return (uint32_t)std::max<size_t>(64, (b->entry_points.size() + 63) / 64 * 64);
 }
 static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
-  if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
   // measured: +5 % on 3 KB rows (C2/C3), -3 % on 512-B rows (the table clear per greedy layer and
-  // the longer probes outweigh the saved L2 atomics when a row costs little): rows >= 1 KB only
+  // the longer probes outweigh the saved L2 atomics when a row costs little; round 2, 5M x 1024 bits:
+  // 0.73-0.91 s against 0.66 s): rows > 1 KB only — the specialised short-row kernels are compiled
+  // without the table
   if ((size_t)b->g.n16 * 16 <= 1024) return 0;
+  if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
   const size_t fixed = hnyk_walk_lds_bytes(rcap, eps_cap_of(b));
   if (fixed + 512 * 4 > 10240) return 512;
   return (uint32_t)((10240 - fixed) / 4 / 64 * 64);
@@ -1426,15 +1432,43 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   // every inserted item owns a (possibly empty) record on layers 0..=level (add_in_layers_below,
   // hnsw.rs:419-424); after an incremental build every surviving old record is rewritten too
   // (fill_gaps_from_deleted puts it in memory, :398/:410) and deleted items own nothing
-  // (delete_links_from_db, writer.rs:692-718)
+  // (delete_links_from_db, writer.rs:692-718).  Which records exist never changes during a builder's
+  // life: the record table (first record of every slot, item id and layer of every record) is
+  // computed once and reused by every finish().
   auto rec_mask = [&](uint32_t s) -> uint32_t {
     if (b->deleted[s]) return 0u;
     uint32_t m = b->old_mask[s];
     if (b->ins_level[s] >= 0) m |= (2u << b->ins_level[s]) - 1u;
     return m;
   };
-  std::vector<uint64_t> rec_first(n + 1, 0);
-  for (uint32_t s = 0; s < n; s++) rec_first[s + 1] = rec_first[s] + (uint32_t)__builtin_popcount(rec_mask(s));
+  unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency() / 2));
+  if (n < 10000) nt = 1;
+  auto parallel = [&](auto &&fn) { // fn(thread, lo, hi) over the slots
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++)
+      th.emplace_back(fn, t, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt));
+    fn(0u, 0u, (uint32_t)((uint64_t)n / nt));
+    for (auto &t : th) t.join();
+  };
+  if (b->rec_first.size() != (size_t)n + 1) {
+    b->rec_first.assign((size_t)n + 1, 0);
+    for (uint32_t s = 0; s < n; s++) b->rec_first[s + 1] = b->rec_first[s] + (uint32_t)__builtin_popcount(rec_mask(s));
+    const uint64_t nr = b->rec_first[n];
+    b->rec_item_t.resize(nr);
+    b->rec_layer_t.resize(nr);
+    parallel([&](unsigned, uint32_t lo, uint32_t hi) {
+      for (uint32_t s = lo; s < hi; s++) {
+        uint64_t r = b->rec_first[s];
+        for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++)
+          if (m & 1) {
+            b->rec_item_t[r] = b->ids[s];
+            b->rec_layer_t[r] = (uint8_t)l;
+            r++;
+          }
+      }
+    });
+  }
+  const std::vector<uint64_t> &rec_first = b->rec_first;
   const uint64_t nrec = rec_first[n];
   // the graph owns its arrays from the start, so that every error return below frees them
   std::unique_ptr<hny_graph, void (*)(hny_graph *)> gh((hny_graph *)calloc(1, sizeof(hny_graph)), hny_graph_free);
@@ -1453,43 +1487,57 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->rec_offset = rec_off;
   rec_off[0] = 0;
   HIP_TRY(hipEventSynchronize(ev_counts));
-  for (uint32_t s = 0; s < n; s++) { // offsets: sequential prefix over the device-computed counts
-    uint64_t r = rec_first[s];
-    for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++) {
-      if (!(m & 1)) continue;
-      uint32_t c = l == 0 ? b->h_cnt0[s] : b->h_cntu[(size_t)b->upper_idx[s] * upl + (l - 1)];
-      rec_off[r + 1] = rec_off[r] + c;
-      r++;
+  // offsets = prefix sum over the device-computed counts, in record order: per-thread sums of a slot
+  // range, a scan of those, then every thread fills its range (the record table is copied alongside)
+  auto count_of = [&](uint32_t s, uint32_t l) -> uint32_t {
+    return l == 0 ? b->h_cnt0[s] : b->h_cntu[(size_t)b->upper_idx[s] * upl + (l - 1)];
+  };
+  std::vector<uint64_t> part(nt + 1, 0);
+  parallel([&](unsigned t, uint32_t lo, uint32_t hi) {
+    uint64_t sum = 0;
+    for (uint32_t s = lo; s < hi; s++)
+      for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++)
+        if (m & 1) sum += count_of(s, l);
+    part[t + 1] = sum;
+    if (hi > lo) {
+      memcpy(rec_item + rec_first[lo], b->rec_item_t.data() + rec_first[lo], (rec_first[hi] - rec_first[lo]) * 4);
+      memcpy(rec_layer + rec_first[lo], b->rec_layer_t.data() + rec_first[lo], rec_first[hi] - rec_first[lo]);
     }
-  }
+  });
+  for (unsigned t = 0; t < nt; t++) part[t + 1] += part[t];
+  parallel([&](unsigned t, uint32_t lo, uint32_t hi) {
+    uint64_t off = part[t];
+    for (uint32_t s = lo; s < hi; s++) {
+      uint64_t r = rec_first[s];
+      for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++)
+        if (m & 1) {
+          off += count_of(s, l);
+          rec_off[++r] = off;
+        }
+    }
+  });
   uint32_t *nbrs = (uint32_t *)malloc(std::max<uint64_t>(rec_off[nrec], 1) * 4);
   if (!nbrs) return fail(HNY_ERR_OOM, "out of host memory for %llu links", (unsigned long long)rec_off[nrec]);
   g->neighbours = nbrs;
   HIP_TRY(hipStreamSynchronize(b->stream)); // the lists have arrived
-  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (n < 10000) nt = 1;
-  auto work = [&](uint32_t lo, uint32_t hi) {
+  const bool identity = !b->incremental && n && b->ids[n - 1] == n - 1; // ids 0..n-1: slot == item id
+  parallel([&](unsigned, uint32_t lo, uint32_t hi) {
     for (uint32_t s = lo; s < hi; s++) {
       uint64_t r = rec_first[s];
       for (uint32_t m = rec_mask(s), l = 0; m; m >>= 1, l++) {
         if (!(m & 1)) continue;
-        rec_item[r] = b->ids[s];
-        rec_layer[r] = (uint8_t)l;
         const u32 *src = l == 0 ? &l0[(size_t)s * M0]
                                 : &up[((size_t)b->upper_idx[s] * upl + (l - 1)) * M];
-        uint32_t c = (uint32_t)(rec_off[r + 1] - rec_off[r]);
+        const uint32_t c = (uint32_t)(rec_off[r + 1] - rec_off[r]);
         uint32_t *dst = nbrs + rec_off[r];
-        for (uint32_t k = 0; k < c; k++) dst[k] = b->ids[src[k]]; // slot -> item id (order kept)
+        if (identity)
+          memcpy(dst, src, (size_t)c * 4);
+        else
+          for (uint32_t k = 0; k < c; k++) dst[k] = b->ids[src[k]]; // slot -> item id (order kept)
         r++;
       }
     }
-  };
-  {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-      th.emplace_back(work, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt));
-    for (auto &t : th) t.join();
-  }
+  });
   uint32_t *eps = (uint32_t *)malloc(std::max<size_t>(b->entry_points.size(), 1) * 4);
   for (size_t i = 0; i < b->entry_points.size(); i++) eps[i] = b->ids[b->entry_points[i]];
   g->n_records = nrec;

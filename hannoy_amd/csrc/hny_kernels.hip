@@ -1237,8 +1237,12 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   // (for short rows, which have no LDS table, the same table in GLOBAL memory — L2 / Infinity-Cache
   // resident, 16-32 KB per wave — in front of the bitset was measured too: C5 walk 0.71 s against
   // 0.69-0.75, C4-like 0.88 against 0.88: no gain, DESIGN.md §5 "Short rows")
+  // rows <= 1 KB never get an LDS table (the host passes vis_slots = 0 for them): say so at compile
+  // time in the specialised kernels, so that the table's code and its six wave-uniform fields go
+  constexpr bool NO_TAB = SP != 0 && NCH == 1;
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
-               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u), a.vis_slots);
+               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u),
+               NO_TAB ? 0u : a.vis_slots);
   u64 evals = 0;
   u32 err_iter = 0, log_over_cnt = 0;
 

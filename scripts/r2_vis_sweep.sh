@@ -1,3 +1,4 @@
+# (historic: ran on the kernels of commit e1860fe, where HNY_VIS_SLOTS still reached the short-row kernels)
 # one-wave-per-query walk with an LDS visited table in front of the HBM bitset, rows <= 1 KB (C5 / C4-like)
 mkdir -p gpurun_out
 for vs in 0 768 1280 1792 2304; do
