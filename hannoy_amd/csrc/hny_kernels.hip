@@ -851,6 +851,20 @@ __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u
   }
 }
 
+// The same batched merge for a beam that LIVES in LDS (ef 128..255, C3's efC = 200): its 64-entry
+// chunks are pulled into registers for the duration of the merge only — beam_merge_rb scatters the
+// merged array back into s.res, which is where this beam lives anyway.  (A register beam kept across
+// the whole expansion was measured slower for 4 chunks: its 8 registers are live while the row loads
+// of the distance pass need the file.)  One rank pass per accepted key instead of a rank loop plus a
+// shift loop with two LDS round trips per 64 entries.
+template <int RC>
+__device__ __forceinline__ void beam_merge_lds(Beam &s, bool acc, u64 key, int ef) {
+  BeamR<RC> r;
+#pragma unroll
+  for (int c = 0; c < RC; c++) r.r[c] = (int)threadIdx.x + 64 * c < s.res_len ? s.res[threadIdx.x + 64 * c] : 0ull;
+  beam_merge_rb<RC>(s, r, acc, key, ef);
+}
+
 // visited set of one query (RoaringBitmap `visited`, hnsw.rs:471 / `path`, reader.rs:726).  First
 // level: an open-addressing hash table in LDS (a query marks ~1e3 of the N items, so a per-wave
 // N-bit set in HBM costs one scattered L2 atomic per neighbour looked at and a dirty 128-B line per
@@ -967,7 +981,8 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
 // QN != NCH: the query is held 8 lanes per row (dist_rows_narrow)
-template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH> // RC: 64-entry chunks of a register beam, 0 = LDS beam
+// LMERGE: the LDS beam (RC == 0) takes the accepted keys of an expansion in one batched merge
+template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH, bool LMERGE = false> // RC: 64-entry chunks of a register beam, 0 = LDS beam
 __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[QN], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
@@ -1171,6 +1186,11 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
           beam_merge_rb<RCN>(s, rb, acc, ((u64)fbits(myd) << 32) | ((u64)myid << 1), ef);
           amask = 0ull;
         }
+      } else if constexpr (LMERGE) {
+        if (__popcll(amask) >= 2 && s.rcap <= 256) { // one key: the plain insert is cheaper (0.610 vs 0.602 s at C3)
+          beam_merge_lds<4>(s, acc, ((u64)fbits(myd) << 32) | ((u64)myid << 1), ef);
+          amask = 0ull;
+        }
       }
 #ifdef HNY_DEBUG_COUNTS
       if (ln == 0) { atomicAdd(&g.stats[10], (u64)__popcll(amask)); atomicAdd(&g.stats[11], (u64)(s.res_len < ef ? 1 : 0)); }
@@ -1205,6 +1225,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   // rows of 9..32 units in the specialised kernels: 8 lanes per row (dist_rows_narrow)
   constexpr bool NARROW = SP != 0 && NCH == 1 && (LPR == 16 || LPR == 32);
   constexpr int QN = NARROW ? LPR / 8 : NCH;
+  constexpr bool LMERGE = SP != 0 && RC == 0 && !BIG_EPS; // specialised kernels with the beam in LDS
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
@@ -1304,7 +1325,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH, BIG_EPS, RC, QN>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+      walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                    nb_d, evals, err_iter, qrow, rb);
       if (last) break;
       // :305-306 eps = [closest]
@@ -1371,7 +1392,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
