@@ -263,7 +263,7 @@ def main():
                                f"{a.data} synthetic vectors resident in HBM, 1 step = 1 full build",
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
                    "batch_frac": builder.opts.batch_frac or 1.0,
-                   "batch_max": builder.opts.batch_max or 65536,
+                   "batch_max": builder.opts.batch_max or H.default_batch_max(a.n),
                    "parallelism": f"item-sharded search x{world}, replicated graph",
                    "distance_order": "x86 (strict)" if a.x86_order else "wave"},
         "roofline": roof,

@@ -28,7 +28,7 @@ EXPORTED = [
     "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
     "hny_builder_nns", "hny_draw_levels_from_seed", "hny_builder_load",
     "hny_builder_apply_begin", "hny_builder_apply_deferred", "hny_builder_apply_merge",
-    "hny_builder_exch_stride_u64", "hny_builder_stream",
+    "hny_builder_exch_stride_u64", "hny_builder_stream", "hny_default_batch_max",
     "hny_lmdb_writer_open", "hny_lmdb_writer_put", "hny_lmdb_writer_finish", "hny_lmdb_writer_abort",
     "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
 ]
@@ -224,6 +224,14 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def default_batch_max(n_items):
+    """what batch_max = 0 selects for an index of n_items (hny_default_batch_max)"""
+    L = load_library()
+    L.hny_default_batch_max.restype = C.c_uint32
+    L.hny_default_batch_max.argtypes = [C.c_uint64]
+    return int(L.hny_default_batch_max(int(n_items)))
 
 
 def draw_levels(seed, M, n):

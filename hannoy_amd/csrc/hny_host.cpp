@@ -458,6 +458,16 @@ int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out) {
   return HNY_OK;
 }
 
+// the default cap of the batch schedule: the largest power of two <= n / 12, at least 65 536.  At 1M
+// items that is the 65 536 whose recall was validated against CPU-built indexes; the
+// cap grows with the index so that a batch stays the same small fraction of it (5M: 262 144, 10M:
+// 524 288) — fewer, larger launches, same relative staleness (C5: recall@10 0.635 vs 0.631).
+uint32_t hny_default_batch_max(uint64_t n_items) {
+  uint32_t b = 65536u;
+  while ((uint64_t)b * 2 * 12 <= n_items && b < (1u << 22)) b *= 2;
+  return b;
+}
+
 uint32_t hny_batch_size(double frac, uint32_t bmax, uint64_t n_done) {
   if (bmax == 0) return 1;
   double v = std::floor(frac * (double)n_done);
@@ -611,7 +621,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   auto b = std::unique_ptr<hny_builder, void (*)(hny_builder *)>(new hny_builder(), hny_builder_destroy);
   b->o = o;
   b->frac = o.batch_frac > 0.0 ? o.batch_frac : 1.0;
-  b->bmax = o.batch_max ? o.batch_max : 65536u;
+  b->bmax = o.batch_max ? o.batch_max : hny_default_batch_max(items->n);
   b->incremental = inc != nullptr;
   uint32_t n16;
   int rc = pick_shape(o.metric, o.dim, b->shape, n16);

@@ -72,7 +72,8 @@ typedef struct {
   void *progress_ctx;
   /* batch-synchronous insertion schedule: batch = clamp(floor(batch_frac * n_inserted), 1,
    * batch_max).  batch_max = 1 reproduces strictly sequential insertion (the reference with one
-   * rayon thread, src/tests/mod.rs:105).  0 / 0.0 select the defaults. */
+   * rayon thread, src/tests/mod.rs:105).  0 / 0.0 select the defaults: batch_frac 1.0,
+   * batch_max hny_default_batch_max(n). */
   double batch_frac;
   uint32_t batch_max;
   int32_t device;            /* HIP device ordinal; -1 = current */
@@ -213,6 +214,9 @@ int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out);
 int hny_draw_levels_from_seed(const uint8_t seed[32], uint64_t skip, uint32_t M, uint64_t n, uint8_t *out);
 /* the schedule: batch size when n_done items are already inserted */
 uint32_t hny_batch_size(double batch_frac, uint32_t batch_max, uint64_t n_done);
+/* what batch_max = 0 selects for an index of n_items: the largest power of two <= n_items / 12, at
+ * least 65 536 (a batch stays the same small fraction of the index as it grows) */
+uint32_t hny_default_batch_max(uint64_t n_items);
 
 /* ---- distances (trait Distance::distance, src/distance/mod.rs:41): pairs of stored items ---- */
 int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot_a,

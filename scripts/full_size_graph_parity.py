@@ -55,17 +55,18 @@ def main():
         levels = H.draw_levels(42, M, n)  # what hny_build draws from StdRng::seed_from_u64(42)
         items.levels = levels
         t0 = time.perf_counter()
+        bmax = H.default_batch_max(n)  # what batch_max = 0 selects: 65 536 at 1M, 262 144 at 5M
         g = H.build(items, M=M, M0=2 * M, ef_construction=ef, seed=42)
         t_gpu = time.perf_counter() - t0
         ds = orc.Dataset(metric, dim, items.ids, items.codes, items.headers, levels)
         t0 = time.perf_counter()
         o = orc.build(ds, M=M, M0=2 * M, ef=ef, order=orc.ORDER_WAVE, threads=cores, batch_frac=1.0,
-                      batch_max=65536)
+                      batch_max=bmax)
         t_cpu = time.perf_counter() - t0
         same = (np.array_equal(g.rec_item, o.rec_item) and np.array_equal(g.rec_layer, o.rec_layer)
                 and np.array_equal(g.offsets, o.offsets) and np.array_equal(g.nbrs, o.nbrs)
                 and g.entry_points.tolist() == o.entry_points.tolist() and g.max_level == o.max_level)
-        res = {"config": f"{name}: {n} x {dim} {mname}, M={M} M0={2 * M} efC={ef}, clustered synthetic data, seed 42",
+        res = {"config": f"{name}: {n} x {dim} {mname}, M={M} M0={2 * M} efC={ef}, clustered synthetic data, seed 42, default schedule (batch_max {bmax})",
                "graphs_identical": bool(same), "records": int(len(g.rec_item)), "links": int(len(g.nbrs)),
                "n_links_added": [int(g.n_links_added), int(o.n_links_added)],
                "n_evals_walk": [int(g.n_evals_walk), int(o.n_evals_walk)],
