@@ -464,7 +464,7 @@ int hny_draw_levels(uint64_t seed, uint32_t M, uint64_t n, uint8_t *out) {
 // 524 288) — fewer, larger launches, same relative staleness (C5: recall@10 0.635 vs 0.631).
 uint32_t hny_default_batch_max(uint64_t n_items) {
   uint32_t b = 65536u;
-  while ((uint64_t)b * 2 * 12 <= n_items && b < (1u << 22)) b *= 2;
+  while ((uint64_t)b * 2 * 12 <= n_items && b < (1u << 21)) b *= 2; // 2^21 x 64 x 2 link ops < 2^29
   return b;
 }
 

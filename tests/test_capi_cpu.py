@@ -159,6 +159,14 @@ def test_kv_records_kat1_bytes(hny, orc, kat):
     assert len(recs) == 2 + 9 + 6
 
 
+def test_default_batch_cap_scales_with_the_index(hny):
+    """batch_max = 0: the largest power of two <= n / 12, at least 65 536 (include/hannoy_amd.h)."""
+    f = hny.default_batch_max
+    assert [f(n) for n in (0, 1, 10_000, 1_000_000, 1_572_863, 1_572_864, 5_000_000, 10_000_000)] == \
+        [65536, 65536, 65536, 65536, 65536, 131072, 262144, 524288]
+    assert f(10 ** 12) == 1 << 21  # bounded: 2^21 members x 64 slots x 2 link ops < 2^29 sequence numbers
+
+
 def test_roaring_serialisation_shapes(hny, orc):
     """RoaringFormatSpec facts: empty bitmap = 8 bytes; array container up to 4096 values, bitmap
     container (8 KiB) above; several 64Ki-containers; u32::MAX."""
