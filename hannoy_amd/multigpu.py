@@ -113,9 +113,13 @@ class Driver:
             self.n_collectives += 1
             self._sync_collective()
             return
-        with self._on_builder_stream():  # no host synchronisation: stream order does it
-            mine = full[self.rank * w:(self.rank + 1) * w].clone()
-            self.dist.all_gather_into_tensor(full[:self.world * w], mine)
+        try:
+            with self._on_builder_stream():  # no host synchronisation: stream order does it
+                mine = full[self.rank * w:(self.rank + 1) * w].clone()
+                self.dist.all_gather_into_tensor(full[:self.world * w], mine)
+        except (RuntimeError, TypeError, ValueError):  # a backend that refuses the external stream:
+            self._ext = None                           # host-synchronised exchange from here on
+            return self._all_gather(full, words_per_rank)
         self.n_collectives += 1
 
     def _sync_collective(self):
