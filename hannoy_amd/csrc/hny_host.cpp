@@ -602,7 +602,14 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   if (o.metric < 0 || o.metric > HNY_BQ_MANHATTAN) return fail(HNY_ERR_INVALID_ARG, "bad metric");
   if (o.dim == 0) return fail(HNY_ERR_INVALID_DIM, "dim must be > 0");
   if (o.M == 0 || o.M0 < o.M) return fail(HNY_ERR_INVALID_ARG, "need 1 <= M <= M0");
-  if (o.M0 > HNY_MAX_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_MAX_CAP);
+  if (o.M > HNY_MAX_CAP) return fail(HNY_ERR_UNSUPPORTED, "M %u > %d", o.M, HNY_MAX_CAP);
+  if (o.M0 > HNY_BIG_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_BIG_CAP);
+  // 64 < M0 <= 256: lists are walked 64 slots at a time and the workgroup kernels hold them whole;
+  // the one-wave kernels (incremental builds: fill_gaps_from_deleted; strict mode) keep one lane per slot
+  const bool bigcap = o.M0 > HNY_MAX_CAP;
+  if (bigcap && ((inc && !inc->load_only) || o.x86_order))
+    return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: fresh builds in the wave order only (no incremental build, no x86_order)",
+                o.M0, HNY_MAX_CAP);
   if (o.ef_construction == 0 || o.ef_construction > HNY_MAX_EF)
     return fail(HNY_ERR_UNSUPPORTED, "ef_construction %u outside [1, %d]", o.ef_construction,
                 HNY_MAX_EF);
@@ -821,6 +828,9 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     // the workgroup prune kernels carry their own wave-order arithmetic: strict mode and very long
     // rows use the single-wave kernels, which all go through dist_rows
     b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0 || b->shape.nch > 8 || o.x86_order;
+    if (bigcap && b->wave_prune_only)
+      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d needs the workgroup prune kernels (rows <= 8 KB, HNY_PRUNE_WAVE unset)",
+                  o.M0, HNY_MAX_CAP);
     b->prune_nw = env_int("HNY_PRUNE_NW", 4) == 8 ? 8 : 4;
   }
 

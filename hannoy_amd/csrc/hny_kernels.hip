@@ -982,7 +982,9 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
 // QN != NCH: the query is held 8 lanes per row (dist_rows_narrow)
 // LMERGE: the LDS beam (RC == 0) takes the accepted keys of an expansion in one batched merge
-template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH, bool LMERGE = false> // RC: 64-entry chunks of a register beam, 0 = LDS beam
+// PAGED: lists of more than 64 slots (64 < M0 <= 256) are taken 64 at a time — the general kernels;
+// the specialised ones serve M0 <= 64 and keep the single pass (the loop's live values cost them 0.6 %)
+template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH, bool LMERGE = false, bool PAGED = false> // RC: 64-entry chunks of a register beam, 0 = LDS beam
 __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[QN], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
@@ -1136,7 +1138,11 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       u32 cap;
       const u32 *nl = pass == 0 ? disk_ids(g, layer, cslot, cap) : nbr_ids(g, layer, cslot, cap);
       if (!nl) continue;
-      u32 id = (u32)ln < cap ? nl[ln] : HNY_SENT;
+      // a list of more than 64 slots (64 < M0 <= 256) is taken 64 at a time, in list order: f_max stays
+      // the one captured at the pop, the visited set carries over, so the outcome is the sequential one
+      for (u32 c0 = 0; c0 < (PAGED ? cap : 1u); c0 += 64u) {
+      const u32 pcap = PAGED ? (cap - c0 < 64u ? cap - c0 : 64u) : cap;
+      u32 id = (u32)ln < pcap ? nl[(PAGED ? c0 : 0u) + ln] : HNY_SENT;
       bool valid = id != HNY_SENT;
       bool isnew = visited_insert(vis, id, valid);
       u64 nmask = __ballot(isnew);
@@ -1154,7 +1160,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         WSYNC();
         int firstj = ln;
         bool anynew = isnew;
-        for (int j = 0; j < (int)cap; j++) {
+        for (int j = 0; j < (int)pcap; j++) {
           u32 oj = nb_ids[j];
           if (valid && oj == id) {
             if (j < firstj) firstj = j;
@@ -1203,6 +1209,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         if constexpr (RB) beam_insert_rb<RCN>(s, rb, ((u64)db << 32) | ((u64)idr << 1), ef);
         else beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
       }
+      } // pages of the list
     }
   }
 }
@@ -1226,6 +1233,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   constexpr bool NARROW = SP != 0 && NCH == 1 && (LPR == 16 || LPR == 32);
   constexpr int QN = NARROW ? LPR / 8 : NCH;
   constexpr bool LMERGE = SP != 0 && RC == 0 && !BIG_EPS; // specialised kernels with the beam in LDS
+  constexpr bool PAGED = SP == 0;                          // general kernels: M0 up to HNY_BIG_CAP
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
@@ -1325,7 +1333,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+      walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                    nb_d, evals, err_iter, qrow, rb);
       if (last) break;
       // :305-306 eps = [closest]
@@ -1392,7 +1400,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
@@ -1585,7 +1593,8 @@ __device__ int visit_filtered(const GraphDev &g, const float4 (&q)[NCH], float q
       u32 cap;
       const u32 *nl = pass == 0 ? disk_ids(g, 0u, cslot, cap) : nbr_ids(g, 0u, cslot, cap);
       if (!nl) continue;
-      u32 id = (u32)ln < cap ? nl[ln] : HNY_SENT;
+      for (u32 c0 = 0; c0 < cap; c0 += 64u) { // lists of more than 64 slots: 64 at a time, in order
+      u32 id = c0 + (u32)ln < cap ? nl[c0 + ln] : HNY_SENT;
       bool valid = id != HNY_SENT;
       bool isnew = visited_insert(vis, id, valid); // path.insert(point), :347
       u64 nmask = __ballot(isnew);
@@ -1611,6 +1620,7 @@ __device__ int visit_filtered(const GraphDev &g, const float4 (&q)[NCH], float q
           if (in_filter(filter, excl, idr)) sorted_insert(res, res_len, ((u64)db << 32) | idr, ef, rcap, res_err);
         }
       }
+      } // pages of the list
     }
   }
   return 0;
@@ -2084,16 +2094,21 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
   return s_len;
 }
 
-__host__ __device__ inline size_t wg_prune_lds_bytes(u32 rcap, u32 row_stride, int SL, int NW) {
-  return (size_t)rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4) + 96 + (size_t)(SL + NW) * row_stride;
+// capmax: slots of the selected-set arrays = max(M, M0) rounded up to 64 (64, or up to HNY_BIG_CAP)
+__host__ __device__ inline u32 wg_capmax(const GraphDev &g) {
+  const u32 c = g.M0 > g.M ? g.M0 : g.M;
+  return (c + 63u) / 64u * 64u;
+}
+__host__ __device__ inline size_t wg_prune_lds_bytes(u32 rcap, u32 row_stride, int SL, int NW, u32 capmax) {
+  return (size_t)rcap * 8 + (size_t)capmax * (8 + 4 + 4) + 96 + (size_t)(SL + NW) * row_stride;
 }
 
-__device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL, u32 row_stride, int NW) {
+__device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL, u32 row_stride, int NW, u32 capmax) {
   WgPruneLds L;
   L.S = reinterpret_cast<u64 *>(base);
-  L.s_ids = reinterpret_cast<u32 *>(L.S + HNY_MAX_CAP);
-  L.s_norm = reinterpret_cast<float *>(L.s_ids + HNY_MAX_CAP);
-  L.surv = reinterpret_cast<int *>(L.s_norm + HNY_MAX_CAP);
+  L.s_ids = reinterpret_cast<u32 *>(L.S + capmax);
+  L.s_norm = reinterpret_cast<float *>(L.s_ids + capmax);
+  L.surv = reinterpret_cast<int *>(L.s_norm + capmax);
   L.vmask = reinterpret_cast<u32 *>(L.surv + 8);
   L.cnorm = reinterpret_cast<float *>(L.vmask + 8);
   L.cbuf = reinterpret_cast<unsigned char *>(L.cnorm + 8);
@@ -2108,7 +2123,7 @@ __global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g_in, PruneArgs a
   specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *list = reinterpret_cast<u64 *>(smem);
-  WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride, NW);
+  WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride, NW, wg_capmax(g));
   const int tid = threadIdx.x;
   u64 evals = 0;
   for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
@@ -2374,9 +2389,10 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
   GraphDev g = g_in;
   specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
-  u64 *lk = reinterpret_cast<u64 *>(smem);          // [HNY_MAX_CAP] the node's list
-  u64 *sorted = lk + HNY_MAX_CAP;                   // [HNY_MAX_CAP]
-  WgPruneLds L = wg_prune_carve(smem + (size_t)2 * HNY_MAX_CAP * 8, SL, g.row_stride, 4);
+  const u32 capmax = wg_capmax(g);
+  u64 *lk = reinterpret_cast<u64 *>(smem);          // [capmax] the node's list
+  u64 *sorted = lk + capmax;                        // [capmax]
+  WgPruneLds L = wg_prune_carve(smem + (size_t)2 * capmax * 8, SL, g.row_stride, 4, capmax);
   const int tid = threadIdx.x;
   const u32 n_def = *a.n_deferred;
   u64 evals = 0;
@@ -2485,11 +2501,11 @@ __global__ __launch_bounds__(64) void k_apply_merge(GraphDev g, const u64 *exch,
       dist = g.up_dist + u * g.M;
       cntp = g.up_cnt + u;
     }
-    if ((u32)ln < cap) {
-      const bool on = ln < cnt;
-      const u64 e = on ? rec[2 + ln] : 0ull;
-      ids[ln] = on ? (u32)(e & 0xFFFFFFFFull) : HNY_SENT;
-      dist[ln] = on ? __uint_as_float((u32)(e >> 32)) : 0.f;
+    for (u32 e0 = (u32)ln; e0 < cap; e0 += 64u) {
+      const bool on = (int)e0 < cnt;
+      const u64 e = on ? rec[2 + e0] : 0ull;
+      ids[e0] = on ? (u32)(e & 0xFFFFFFFFull) : HNY_SENT;
+      dist[e0] = on ? __uint_as_float((u32)(e >> 32)) : 0.f;
     }
     if (ln == 0) *cntp = cw;
   }
@@ -2669,25 +2685,37 @@ __global__ __launch_bounds__(64) void k_pair_distances(GraphDev g, const u32 *pa
 // occurrences by broadcast compare.  This is also the order Reader::visit iterates a Links bitmap
 // in (reader.rs:343-346), so the k-NN search runs on the finalised lists.
 __global__ __launch_bounds__(64) void k_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap) {
-  __shared__ u32 sh[64];
-  __shared__ u32 fst[64];
+  __shared__ u32 sh[HNY_BIG_CAP];
+  __shared__ u32 fst[HNY_BIG_CAP];
   const int ln = threadIdx.x;
   for (u32 li = blockIdx.x; li < n_lists; li += gridDim.x) {
     u32 *row = ids + (size_t)li * cap;
-    const u32 v = (u32)ln < cap ? row[ln] : HNY_SENT;
-    sh[ln] = v;
+    // (cap <= 64: every loop below runs once, one slot per lane)
+    for (u32 e = (u32)ln; e < cap; e += 64u) {
+      sh[e] = row[e];
+      row[e] = HNY_SENT;
+    }
     WSYNC();
-    bool first = v != HNY_SENT;
-    for (int j = 0; j < ln; j++) first = first && sh[j] != v;
-    fst[ln] = first ? 1u : 0u;
+    for (u32 e = (u32)ln; e < cap; e += 64u) {
+      const u32 v = sh[e];
+      bool first = v != HNY_SENT;
+      for (u32 j = 0; j < e; j++) first = first && sh[j] != v;
+      fst[e] = first ? 1u : 0u;
+    }
     WSYNC();
-    int pos = 0;
-    for (u32 j = 0; j < cap; j++) pos += (fst[j] != 0u && sh[j] < v) ? 1 : 0;
-    const u64 keep = __ballot(first);
-    if ((u32)ln < cap) row[ln] = HNY_SENT;
-    WSYNC();
-    if (first) row[pos] = v;
-    if (ln == 0) cnt_out[li] = (u32)__popcll(keep);
+    u32 kept = 0;
+    for (u32 e0 = 0; e0 < cap; e0 += 64u) { // uniform trip count: the ballot below needs every lane
+      const u32 e = e0 + (u32)ln;
+      const bool first = e < cap && fst[e] != 0u;
+      if (first) {
+        const u32 v = sh[e];
+        int pos = 0;
+        for (u32 j = 0; j < cap; j++) pos += (fst[j] != 0u && sh[j] < v) ? 1 : 0;
+        row[pos] = v; // rank among the first occurrences: every slot was cleared above
+      }
+      kept += (u32)__popcll(__ballot(first));
+    }
+    if (ln == 0) cnt_out[li] = kept;
     WSYNC();
   }
 }
@@ -2862,7 +2890,7 @@ struct Hot {
       if constexpr (C > 8) {
         return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
       } else {
-        size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL, nw);
+        size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL, nw, wg_capmax(g));
         if constexpr (SP == 0) {
           if (nw == 8) {
             hipLaunchKernelGGL((k_prune_wg<L, C, 8, 0>), dim3(grid), dim3(512), lds, st, g, a, SL);
@@ -2880,7 +2908,7 @@ struct Hot {
       if constexpr (C > 8) {
         return hipErrorInvalidValue;
       } else {
-        size_t lds = wg_prune_lds_bytes(2 * HNY_MAX_CAP, g.row_stride, SL, 4);
+        size_t lds = wg_prune_lds_bytes(2 * wg_capmax(g), g.row_stride, SL, 4, wg_capmax(g));
         hipLaunchKernelGGL((k_apply_wg<L, C, SP>), dim3(grid), dim3(256), lds, st, g, a, SL);
         return hipGetLastError();
       }
@@ -2979,7 +3007,7 @@ hipError_t HNY_CAT(hnyk_apply_wg_sp, HNY_PART)(const GraphDev &g, const ApplyArg
 static bool fast_path(const GraphDev &g) {
   const char *e = getenv("HNY_NO_FAST"); // read per launch: tests flip it inside one process
   const bool off = e && atoi(e) != 0;
-  return !off && !g.x86_order && !g.incremental && g.metric >= 0 && g.metric < 7;
+  return !off && !g.x86_order && !g.incremental && g.metric >= 0 && g.metric < 7 && g.M0 <= 64u;
 }
 #define HNY_SP_SWITCH(fn, ...)                 \
   switch (g.metric) {                          \

@@ -1045,16 +1045,67 @@ def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
     _same_graph(gg2, og2)
 
 
-def test_m0_beyond_64_is_refused_loudly(hny):
-    """include/hannoy_amd.h: max(M, M0) <= 64 (one lane per neighbour slot).  The reference's fuzz
-    configuration M = 16, M0 = 768 (src/tests/fuzz.rs:86-87) is out of contract: the build must fail
-    with HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp), while (32, 64), the
-    largest pair of the reference's Python API (python.rs:280), builds."""
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 4000, 64, 16, 96, 64), (1, 3000, 768, 16, 200, 100),
+                                                   (3, 5000, 256, 8, 256, 48), (0, 2500, 20, 64, 128, 150)])
+def test_m0_beyond_64_equals_oracle(orc, hny, metric, n, dim, M, M0, ef):
+    """64 < M0 <= 256 (lists walked 64 slots at a time, workgroup kernels hold them whole): fresh build
+    == oracle edge for edge, with the same walk evaluations, for lists that really fill up beyond 64
+    slots; the k-NN search on that graph == the restated Reader."""
+    rng = np.random.default_rng(n + M0)
+    cent = rng.uniform(-1, 1, (6, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 6, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=M0))
+    kw = dict(batch_frac=0.25, batch_max=1024)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    qs = rng.uniform(-1, 1, (300, dim)).astype(np.float32)
+    qc = orc.encode_vectors(metric, qs)
+    qh = orc.make_headers(metric, dim, qc)
+    with hny.Builder(items, M=M, M0=M0, ef_construction=ef, **kw) as b:
+        b.run()
+        g = b.finish()
+        ids, dists, counts = b.search_knn(qc, qh, k=10, ef_search=64)
+        fids, fd, fc = b.nns(qc[:50], qh[:50], k=5, ef_search=40, candidates=np.arange(0, n, 3, dtype=np.uint32))
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+    deg0 = np.diff(g.offsets.astype(np.int64))[g.rec_layer == 0]
+    assert deg0.max() > 64  # the wide lists are really used
+    oi, od, oc = orc.search(ds, g, qc, qh, k=10, ef_search=64, order=orc.ORDER_WAVE, threads=8)
+    assert np.array_equal(oc, counts) and np.array_equal(oi, ids)
+    assert np.array_equal(od.view(np.uint32), dists.view(np.uint32))
+    oi, od, oc = orc.search(ds, g, qc[:50], qh[:50], k=5, ef_search=40, order=orc.ORDER_WAVE, threads=8,
+                            candidates=np.arange(0, n, 3, dtype=np.uint32))
+    assert np.array_equal(oc, fc) and np.array_equal(oi, fids)
+
+
+def test_m0_beyond_64_native_multi_gpu(orc, hny, monkeypatch):
+    """the sharded link phase with wide lists (exchange records of 2 + M0 words, k_apply_merge over
+    more than 64 slots): three ranks on one GPU == oracle."""
+    monkeypatch.setenv("HNY_MGPU_SHIM", "1")
+    monkeypatch.setenv("HNY_MGPU_VERIFY", "1")
+    monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "16")
+    monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
+    rng = np.random.default_rng(8)
+    n, dim, M, M0, ef = 3000, 48, 16, 80, 64
+    cent = rng.uniform(-1, 1, (4, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 4, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, 1, vecs, draw_levels(n, M, seed=3))
+    kw = dict(batch_frac=0.5, batch_max=512)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, devices=[0, 0, 0], **kw)
+    _same_graph(g, o)
+
+
+def test_m0_limits_are_refused_loudly(orc, hny):
+    """include/hannoy_amd.h: M <= 64, M0 <= 256 for fresh wave-order builds, M0 <= 64 for incremental
+    builds and strict mode.  The reference's fuzz configuration M = 16, M0 = 768 (src/tests/fuzz.rs:86-87)
+    is out of contract: HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
     v = np.random.default_rng(1).uniform(-1, 1, (500, 32)).astype(np.float32)
     items = hny.ItemSet.from_f32(hny.COSINE, v)
-    for M, M0 in ((16, 768), (16, 96), (65, 65)):
+    for kw in (dict(M=16, M0=768), dict(M=65, M0=65), dict(M=16, M0=96, x86_order=True)):
         with pytest.raises(hny.HannoyError) as e:
-            hny.build(items, M=M, M0=M0, ef_construction=32)
+            hny.build(items, ef_construction=32, **kw)
         assert e.value.code == -5
-    g = hny.build(items, M=32, M0=64, ef_construction=32)
-    assert len(g.rec_item) >= 500
+    g = hny.build(items, M=16, M0=96, ef_construction=32)
+    with pytest.raises(hny.HannoyError) as e:  # incremental build on wide lists: not supported
+        hny.build_incremental(items, g, [3], [], M=16, M0=96, ef_construction=32)
+    assert e.value.code == -5
