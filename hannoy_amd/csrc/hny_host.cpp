@@ -812,7 +812,10 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     pos = e;
   }
   if (b->max_ops >= (1ull << HNY_SEQ_BITS))
-    return fail(HNY_ERR_UNSUPPORTED, "batch_max too large: %zu link ops per batch >= 2^%d", b->max_ops, HNY_SEQ_BITS);
+    return fail(HNY_ERR_UNSUPPORTED,
+                "batch_max %u too large for M0 %u: %zu link ops per batch >= 2^%d (pass batch_max <= %u; the schedule "
+                "is part of the result, so it is never shrunk silently)",
+                b->bmax, o.M0, b->max_ops, HNY_SEQ_BITS, (uint32_t)((1ull << (HNY_SEQ_BITS - 1)) / std::max(o.M0, 2 * o.M) / 2));
   // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (5 for binary codes <= 1 KB, see k_walk)
   b->walk_slots = (uint32_t)std::min<int64_t>(
       std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 && o.metric >= HNY_HAMMING ? 5120 : 4096)), 65536);
@@ -1733,9 +1736,11 @@ struct SearchCancel {
   int (*fn)(void *) = nullptr;
   void *ctx = nullptr;
   u32 *h = nullptr, *d = nullptr;
+  hipEvent_t ev = nullptr; // its own event: searches must not grow the builder's event pool
   bool cancelled = false;
   ~SearchCancel() {
     if (h) (void)hipHostFree(h);
+    if (ev) (void)hipEventDestroy(ev);
   }
   hipError_t init(const hny_query_opts *qo) {
     if (!qo || !qo->cancel) return hipSuccess;
@@ -1744,7 +1749,9 @@ struct SearchCancel {
     hipError_t e = hipHostMalloc((void **)&h, 64, hipHostMallocMapped);
     if (e != hipSuccess) return e;
     *h = 0u;
-    return hipHostGetDevicePointer((void **)&d, h, 0);
+    e = hipHostGetDevicePointer((void **)&d, h, 0);
+    if (e != hipSuccess) return e;
+    return hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   }
   bool probe() { // before a chunk is started
     if (fn && !cancelled && fn(ctx)) {
@@ -1755,10 +1762,7 @@ struct SearchCancel {
   }
   hipError_t wait(hny_builder *b) {
     if (!fn) return hipStreamSynchronize(b->stream);
-    hipEvent_t ev;
-    hipError_t e = next_sync_event(b, &ev);
-    if (e != hipSuccess) return e;
-    e = hipEventRecord(ev, b->stream);
+    hipError_t e = hipEventRecord(ev, b->stream);
     if (e != hipSuccess) return e;
     for (;;) {
       e = hipEventQuery(ev);

@@ -10,7 +10,7 @@ typedef unsigned int u32;
 
 #define HNY_SENT 0xFFFFFFFFu      // empty neighbour slot
 #define HNY_MAX_CAP 64            // max(M, M0) of the one-lane-per-slot kernels (incremental builds, strict mode)
-#define HNY_BIG_CAP 256           // M0 of fresh builds / loaded graphs: lists are walked 64 slots at a time
+#define HNY_BIG_CAP 1024          // M0 of fresh builds / loaded graphs: lists are walked 64 slots at a time
 #define HNY_MAX_EPS 2048          // max entry points (every item of a small all-level-0 index is one)
 #define HNY_POOL_CAP 128          // tie pool (DESIGN.md "candidate heap")
 #define HNY_MAX_EF 512

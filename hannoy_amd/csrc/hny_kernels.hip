@@ -2148,7 +2148,7 @@ __global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g_in, PruneArgs a
     }
     u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
     if (tid == 0) out[0] = (u64)s_len;
-    if (tid < s_len) out[1 + tid] = L.S[tid];
+    for (int e = tid; e < s_len; e += (int)blockDim.x) out[1 + e] = L.S[e];
     __syncthreads();
   }
   if ((tid & 63) == 0 && evals) atomicAdd(&g.stats[ST_EVALS_PRUNE], evals);
@@ -2418,7 +2418,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
     const u32 cw = *cntp;
     int cnt = (int)(cw & 0xFFFFu);
     bool frozen = (cw >> 31) != 0u;
-    if (tid < cnt) lk[tid] = ((u64)fbits(dist[tid]) << 32) | ids[tid];
+    for (int e = tid; e < cnt; e += 256) lk[e] = ((u64)fbits(dist[e]) << 32) | ids[e];
     __syncthreads();
     for (u32 i = i0; i < a.n_ops && !frozen; i++) {
       const u64 key = a.keys[i];
@@ -2430,12 +2430,12 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
         cnt++;
         __syncthreads();
       } else { // :547-552
-        if (tid < cnt) {
-          const u64 mine = lk[tid];
+        for (int e = tid; e < cnt; e += 256) { // (cnt <= 256: one entry per thread)
+          const u64 mine = lk[e];
           int rk = 0;
           for (int j = 0; j < cnt; j++) {
             u64 o = lk[j];
-            rk += (o < mine || (o == mine && j < tid)) ? 1 : 0;
+            rk += (o < mine || (o == mine && j < e)) ? 1 : 0;
           }
           sorted[rk] = mine;
         }
@@ -2449,16 +2449,16 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
         } else {
           s_len = wg_prune<LPR, NCH, 4>(g, sorted, cnt, (int)cap, L, evals);
         }
-        if (tid < s_len) lk[tid] = L.S[tid];
+        for (int e = tid; e < s_len; e += 256) lk[e] = L.S[e];
         cnt = s_len;
         frozen = (s_len == (int)cap);
         __syncthreads();
       }
     }
-    if ((u32)tid < cap) {
-      const bool on = tid < cnt;
-      ids[tid] = on ? (u32)(lk[tid] & 0xFFFFFFFFull) : HNY_SENT;
-      dist[tid] = on ? __uint_as_float((u32)(lk[tid] >> 32)) : 0.f;
+    for (u32 e = (u32)tid; e < cap; e += 256u) {
+      const bool on = (int)e < cnt;
+      ids[e] = on ? (u32)(lk[e] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[e] = on ? __uint_as_float((u32)(lk[e] >> 32)) : 0.f;
     }
     if (tid == 0) *cntp = (u32)cnt | (frozen ? 0x80000000u : 0u);
     if (a.exch) { // the finished list, for the ranks that did not compute it
@@ -2467,7 +2467,7 @@ __global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, in
         rec[0] = k0;
         rec[1] = (u64)((u32)cnt | (frozen ? 0x80000000u : 0u));
       }
-      if (tid < cnt) rec[2 + tid] = lk[tid];
+      for (int e = tid; e < cnt; e += 256) rec[2 + e] = lk[e];
     }
     __syncthreads();
   }
@@ -2897,6 +2897,11 @@ struct Hot {
             return hipGetLastError();
           }
         }
+        if (lds > 65536) { // wide lists (M0 up to HNY_BIG_CAP) next to long rows
+          hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prune_wg<L, C, 4, SP>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (rc != hipSuccess) return rc;
+        }
         hipLaunchKernelGGL((k_prune_wg<L, C, 4, SP>), dim3(grid), dim3(256), lds, st, g, a, SL);
         return hipGetLastError();
       }
@@ -2909,6 +2914,11 @@ struct Hot {
         return hipErrorInvalidValue;
       } else {
         size_t lds = wg_prune_lds_bytes(2 * wg_capmax(g), g.row_stride, SL, 4, wg_capmax(g));
+        if (lds > 65536) {
+          hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_apply_wg<L, C, SP>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (rc != hipSuccess) return rc;
+        }
         hipLaunchKernelGGL((k_apply_wg<L, C, SP>), dim3(grid), dim3(256), lds, st, g, a, SL);
         return hipGetLastError();
       }

@@ -52,14 +52,14 @@ typedef struct {
   int32_t metric;            /* hny_metric */
   uint32_t dim;              /* user dimensions (binary codecs pad to 64, binary.rs:80-94) */
   uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120).  1 <= M <= 64 and
-                              * M <= M0 <= 256 for fresh builds in the wave order (and for loading /
+                              * M <= M0 <= 1024 for fresh builds in the wave order (and for loading /
                               * searching a stored graph); M0 <= 64 for incremental builds and strict
                               * mode, whose one-wave kernels keep one lane per neighbour slot.  That
                               * covers every pair the reference's Python API offers ((4,8) .. (32,64),
-                              * python.rs:280).  OUT OF CONTRACT: the const generics allow any pair
-                              * and the reference's fuzz test builds incrementally with M = 16,
-                              * M0 = 768 (src/tests/fuzz.rs:86-87); such a build returns
-                              * HNY_ERR_UNSUPPORTED — never a silently different graph. */
+                              * python.rs:280) and a fresh build with the pair of the reference's fuzz
+                              * test, M = 16, M0 = 768 (src/tests/fuzz.rs:86-87).  OUT OF CONTRACT:
+                              * that test's INCREMENTAL builds on such lists, and anything wider —
+                              * HNY_ERR_UNSUPPORTED, never a silently different graph. */
   uint32_t ef_construction;  /* default 100 (writer.rs:49) */
   float alpha;               /* default 1.0 (writer.rs:51) */
   uint64_t seed;             /* levels when items.levels == NULL: drawn exactly as the reference

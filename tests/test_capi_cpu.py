@@ -58,10 +58,10 @@ def test_argument_validation(hny):
         hny.build(items, M=16, M0=8)
     assert e.value.code == -1
     with pytest.raises(hny.HannoyError) as e:
-        hny.build(items, M=16, M0=768)  # the reference's fuzz pair (fuzz.rs:86-87): out of contract
+        hny.build(items, M=16, M0=2048)  # beyond HNY_BIG_CAP = 1024
     assert e.value.code == -5
     with pytest.raises(hny.HannoyError) as e:
-        hny.build(items, M=16, M0=128, x86_order=True)  # 64 < M0 <= 256: wave-order fresh builds only
+        hny.build(items, M=16, M0=128, x86_order=True)  # 64 < M0 <= 1024: wave-order fresh builds only
     assert e.value.code == -5
     bad = hny.ItemSet(hny.EUCLIDEAN, 16, items.ids, items.codes, items.headers)  # stride < 16*4
     with pytest.raises(hny.HannoyError) as e:

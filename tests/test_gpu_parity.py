@@ -1046,9 +1046,11 @@ def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
 
 
 @pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 4000, 64, 16, 96, 64), (1, 3000, 768, 16, 200, 100),
-                                                   (3, 5000, 256, 8, 256, 48), (0, 2500, 20, 64, 128, 150)])
+                                                   (3, 5000, 256, 8, 256, 48), (0, 2500, 20, 64, 128, 150),
+                                                   (0, 3000, 32, 16, 768, 100),   # the fuzz pair, fuzz.rs:86-87
+                                                   (1, 1500, 768, 16, 1024, 64)])  # > 64 KB of LDS per workgroup
 def test_m0_beyond_64_equals_oracle(orc, hny, metric, n, dim, M, M0, ef):
-    """64 < M0 <= 256 (lists walked 64 slots at a time, workgroup kernels hold them whole): fresh build
+    """64 < M0 <= 1024 (lists walked 64 slots at a time, workgroup kernels hold them whole): fresh build
     == oracle edge for edge, with the same walk evaluations, for lists that really fill up beyond 64
     slots; the k-NN search on that graph == the restated Reader."""
     rng = np.random.default_rng(n + M0)
@@ -1096,12 +1098,12 @@ def test_m0_beyond_64_native_multi_gpu(orc, hny, monkeypatch):
 
 
 def test_m0_limits_are_refused_loudly(orc, hny):
-    """include/hannoy_amd.h: M <= 64, M0 <= 256 for fresh wave-order builds, M0 <= 64 for incremental
-    builds and strict mode.  The reference's fuzz configuration M = 16, M0 = 768 (src/tests/fuzz.rs:86-87)
-    is out of contract: HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
+    """include/hannoy_amd.h: M <= 64, M0 <= 1024 for fresh wave-order builds, M0 <= 64 for incremental
+    builds and strict mode (so the reference's fuzz pair M = 16, M0 = 768, src/tests/fuzz.rs:86-87, builds
+    fresh but not incrementally): HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
     v = np.random.default_rng(1).uniform(-1, 1, (500, 32)).astype(np.float32)
     items = hny.ItemSet.from_f32(hny.COSINE, v)
-    for kw in (dict(M=16, M0=768), dict(M=65, M0=65), dict(M=16, M0=96, x86_order=True)):
+    for kw in (dict(M=16, M0=1025), dict(M=65, M0=65), dict(M=16, M0=96, x86_order=True)):
         with pytest.raises(hny.HannoyError) as e:
             hny.build(items, ef_construction=32, **kw)
         assert e.value.code == -5
