@@ -28,7 +28,7 @@ EXPORTED = [
     "hny_builder_create_incremental", "hny_builder_fill_gaps", "hny_encode_vectors_gpu",
     "hny_builder_nns", "hny_draw_levels_from_seed", "hny_builder_load",
     "hny_builder_apply_begin", "hny_builder_apply_deferred", "hny_builder_apply_merge",
-    "hny_builder_exch_stride_u64", "hny_builder_stream", "hny_default_batch_max",
+    "hny_builder_exch_stride_u64", "hny_builder_stream", "hny_default_batch_max", "hny_selftest_lane_ops",
     "hny_lmdb_writer_open", "hny_lmdb_writer_put", "hny_lmdb_writer_finish", "hny_lmdb_writer_abort",
     "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
 ]
@@ -232,6 +232,17 @@ def default_batch_max(n_items):
     L.hny_default_batch_max.restype = C.c_uint32
     L.hny_default_batch_max.argtypes = [C.c_uint64]
     return int(L.hny_default_batch_max(int(n_items)))
+
+
+def selftest_lane_ops(device=-1):
+    """hny_selftest_lane_ops: per-lane mismatch masks (all zero = the cross-lane primitives agree with
+    __shfl_xor); raises HannoyError if they do not"""
+    L = load_library()
+    L.hny_selftest_lane_ops.restype = C.c_int
+    L.hny_selftest_lane_ops.argtypes = [C.c_int32, C.POINTER(C.c_uint32)]
+    out = (C.c_uint32 * 64)()
+    _check(L.hny_selftest_lane_ops(int(device), out))
+    return list(out)
 
 
 def draw_levels(seed, M, n):

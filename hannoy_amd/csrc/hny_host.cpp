@@ -530,6 +530,25 @@ int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *ve
 
 // the same on the device: codes through k_quantize, Cosine norms through k_norms_x86 (bit-identical
 // to the host path above), streamed in chunks so that any n fits
+int hny_selftest_lane_ops(int32_t device, uint32_t *mismatch64) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(HNY_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  DevBuf<u32> d;
+  HIP_TRY(d.alloc(64));
+  HIP_TRY(hnyk_lane_selftest(d.p, nullptr));
+  uint32_t h[64];
+  HIP_TRY(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
+  uint32_t any = 0;
+  for (int i = 0; i < 64; i++) {
+    any |= h[i];
+    if (mismatch64) mismatch64[i] = h[i];
+  }
+  if (any) return fail(HNY_ERR_DEVICE, "cross-lane primitives disagree with __shfl_xor: mask 0x%08x", any);
+  return HNY_OK;
+}
+
 int hny_encode_vectors_gpu(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
                            void *out_codes, void *out_headers, int32_t device) {
   if (!vectors || !out_codes || !out_headers || metric < 0 || metric > HNY_BQ_MANHATTAN || dim == 0)

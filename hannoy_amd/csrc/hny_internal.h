@@ -234,6 +234,7 @@ hipError_t hnyk_sort_pairs48(void *temp, size_t &temp_bytes, u64 *keys_in, u64 *
 hipError_t hnyk_iota_u64(u64 *p, u32 base, u32 n, hipStream_t st);
 hipError_t hnyk_take_topk(const u64 *cand, const u32 *cand_n, u32 rcap, u32 k, u32 n, u64 *out,
                           hipStream_t st);
+hipError_t hnyk_lane_selftest(u32 *out64, hipStream_t st);
 hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                                LaunchShape s, hipStream_t st);
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);

@@ -164,17 +164,68 @@ __device__ __forceinline__ u32 partial_bin(const float4 (&q)[NCH], const float4 
   return pc;
 }
 
+// value of lane (lane ^ OFF), OFF a power of two: the data movement of __shfl_xor(v, OFF, 64) without
+// its per-call index arithmetic (xor, width clamp, select, shift = 4 VALU instructions in front of
+// every ds_bpermute) and without the trip through the LDS pipe, which queues behind the row reads:
+// 1, 2, 8: one DPP move (quad_perm / row_ror:8; folds into the consuming add); 4: row_half_mirror then
+// quad_perm:[3,2,1,0] (7 - i, then reversed inside its quad = i ^ 4); 16, 32: gfx950's
+// v_permlane16_swap / v_permlane32_swap of the value with itself, then a select.
+template <int OFF>
+__device__ __forceinline__ u32 xshfl_u32(u32 v) {
+  static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "xor lane offset");
+  if constexpr (OFF == 1) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xF, 0xF, false);
+  } else if constexpr (OFF == 2) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xF, 0xF, false);
+  } else if constexpr (OFF == 4) {
+    const int m = __builtin_amdgcn_update_dpp(0, (int)v, 0x141 /*row_half_mirror*/, 0xF, 0xF, false);
+    return (u32)__builtin_amdgcn_update_dpp(0, m, 0x1B /*quad_perm:[3,2,1,0]*/, 0xF, 0xF, false);
+  } else if constexpr (OFF == 8) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /*row_ror:8*/, 0xF, 0xF, false);
+  } else if constexpr (OFF == 16) {
+    // rows of 16 lanes [v0 v1 v2 v3] -> {[v0 v0 v2 v2], [v1 v1 v3 v3]}
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16u) ? r[0] : r[1];
+  } else {
+    // halves [lo hi] -> {[lo lo], [hi hi]}
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32u) ? r[0] : r[1];
+  }
+}
+template <int OFF>
+__device__ __forceinline__ float xshfl(float v) {
+  return __uint_as_float(xshfl_u32<OFF>(__float_as_uint(v)));
+}
+template <int OFF>
+__device__ __forceinline__ u32 xshfl(u32 v) {
+  return xshfl_u32<OFF>(v);
+}
+template <int OFF>
+__device__ __forceinline__ int xshfl(int v) {
+  return (int)xshfl_u32<OFF>((u32)v);
+}
+template <int OFF>
+__device__ __forceinline__ u64 xshfl(u64 v) {
+  return ((u64)xshfl_u32<OFF>((u32)(v >> 32)) << 32) | (u64)xshfl_u32<OFF>((u32)v);
+}
+// v[t] + v[t ^ OFF] for OFF = FROM, FROM/2, ... 1 (the xor butterfly, in that order)
+template <int FROM, typename T>
+__device__ __forceinline__ T xor_sum_from(T v) {
+  if constexpr (FROM >= 1) {
+    v = v + xshfl<FROM>(v);
+    return xor_sum_from<FROM / 2, T>(v);
+  } else {
+    return v;
+  }
+}
+
 template <int LPR>
 __device__ __forceinline__ float butterfly_f32(float v) {
-#pragma unroll
-  for (int off = LPR / 2; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
+  return xor_sum_from<LPR / 2, float>(v);
 }
 template <int LPR>
 __device__ __forceinline__ u32 butterfly_u32(u32 v) {
-#pragma unroll
-  for (int off = LPR / 2; off >= 1; off >>= 1) v = v + (u32)__shfl_xor((int)v, off, 64);
-  return v;
+  return xor_sum_from<LPR / 2, u32>(v);
 }
 
 // Folded butterflies.  The xor butterfly computes, at every step, v[t] + v[t ^ off] on all lanes, so
@@ -183,41 +234,38 @@ __device__ __forceinline__ u32 butterfly_u32(u32 v) {
 // additions (bit-identical result), but 4 rows cost 2+1+(log2(LPR)-2) shuffles instead of
 // 4*log2(LPR).  Row j of a fold4 ends up in the lanes with bit(LPR/2) == (j & 1) and
 // bit(LPR/4) == (j >> 1); fold2: bit(LPR/2) == j.
-template <typename T>
-__device__ __forceinline__ T fold_step(T a, T b, int off) {
-  const bool hi = (threadIdx.x & off) != 0;
-  T keep = hi ? b : a, send = hi ? a : b;
-  T recv;
-  if constexpr (sizeof(T) == 4 && __is_same(T, float))
-    recv = __shfl_xor(send, off, 64);
-  else
-    recv = (T)__shfl_xor((int)send, off, 64);
-  return keep + recv;
+template <int OFF, typename T>
+__device__ __forceinline__ T fold_step(T a, T b) {
+  static_assert(sizeof(T) == 4, "32-bit lanes");
+  if constexpr (OFF == 32 || OFF == 16) {
+    // the swap IS the exchange: {[a.lo b.lo], [a.hi b.hi]} (halves; rows of 16 likewise), and the sum
+    // of the two is keep + recv on every lane (IEEE addition commutes, so the bits are the same)
+    u32 ua, ub;
+    __builtin_memcpy(&ua, &a, 4);
+    __builtin_memcpy(&ub, &b, 4);
+    const auto r = OFF == 32 ? __builtin_amdgcn_permlane32_swap(ua, ub, false, false)
+                             : __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
+    T x, y;
+    const u32 r0 = r[0], r1 = r[1];
+    __builtin_memcpy(&x, &r0, 4);
+    __builtin_memcpy(&y, &r1, 4);
+    return x + y;
+  } else {
+    const bool hi = (threadIdx.x & OFF) != 0;
+    T keep = hi ? b : a, send = hi ? a : b;
+    return keep + xshfl<OFF>(send);
+  }
 }
 template <int LPR, typename T>
 __device__ __forceinline__ T fold4(T p0, T p1, T p2, T p3) {
-  T x01 = fold_step<T>(p0, p1, LPR / 2), x23 = fold_step<T>(p2, p3, LPR / 2);
-  T y = fold_step<T>(x01, x23, LPR / 4);
-#pragma unroll
-  for (int off = LPR / 8; off >= 1; off >>= 1) {
-    if constexpr (__is_same(T, float))
-      y = y + __shfl_xor(y, off, 64);
-    else
-      y = y + (T)__shfl_xor((int)y, off, 64);
-  }
-  return y;
+  T x01 = fold_step<LPR / 2, T>(p0, p1), x23 = fold_step<LPR / 2, T>(p2, p3);
+  T y = fold_step<LPR / 4, T>(x01, x23);
+  return xor_sum_from<LPR / 8, T>(y);
 }
 template <int LPR, typename T>
 __device__ __forceinline__ T fold2(T p0, T p1) {
-  T y = fold_step<T>(p0, p1, LPR / 2);
-#pragma unroll
-  for (int off = LPR / 4; off >= 1; off >>= 1) {
-    if constexpr (__is_same(T, float))
-      y = y + __shfl_xor(y, off, 64);
-    else
-      y = y + (T)__shfl_xor((int)y, off, 64);
-  }
-  return y;
+  T y = fold_step<LPR / 2, T>(p0, p1);
+  return xor_sum_from<LPR / 4, T>(y);
 }
 template <int LPR>
 __device__ __forceinline__ int fold4_row() { // which of the 4 rows this lane's fold4 result belongs to
@@ -1460,14 +1508,16 @@ struct QHeap {
   u64 top;
 };
 
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    u64 o = (u64)__shfl_xor((long long)v, off, 64);
-    v = o < v ? o : v;
+template <int OFF>
+__device__ __forceinline__ u64 wave_min_step(u64 v) {
+  if constexpr (OFF >= 1) {
+    const u64 o = xshfl<OFF>(v);
+    return wave_min_step<OFF / 2>(o < v ? o : v);
+  } else {
+    return v;
   }
-  return v;
 }
+__device__ __forceinline__ u64 wave_min_u64(u64 v) { return wave_min_step<32>(v); }
 
 __device__ __forceinline__ bool qheap_push(QHeap &Q, u64 key) {
   if (Q.size >= Q.cap) return false;
@@ -1945,7 +1995,8 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
                                         u64 &evals) {
   constexpr int RPG = 64 / LPR;
   static_assert(NW == 4 || NW == 8, "chunk of 4 or 8 candidates");
-  const int tid = threadIdx.x, w = tid >> 6, ln = tid & 63, t = ln % LPR, sub = ln / LPR;
+  // (w through readfirstlane: the compiler then knows every per-wave condition below is uniform)
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, t = ln % LPR, sub = ln / LPR;
   const int j4 = fold4_row<LPR>();
   int s_len = 0;
   float4 nxt[NCH];
@@ -1983,21 +2034,42 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
     bool viol = false;
     const int ngroups = (s_len + RPG - 1) / RPG;
     if (have) {
-      for (int g0 = 0; g0 < ngroups && !viol; g0 += 4) {
+      // one pass = 4 load groups of S against the candidate.  Two loops: passes whose rows are all
+      // staged in LDS touch no register a global load may still be writing, so they do not wait for
+      // the next candidate's row (issued in A) — with the two sources mixed per row the compiler put
+      // s_waitcnt vmcnt(0) in front of the first LDS read and that prefetch was exposed on every
+      // chunk.  The rest of S (beyond L.SL rows, rare) comes from L2 / HBM in the second loop.
+      auto pass = [&](const int g0, auto staged_tag) __attribute__((always_inline)) {
+        constexpr bool STAGED = decltype(staged_tag)::value;
+        const int gend = g0 + 4 < ngroups ? g0 + 4 : ngroups;
         float4 r[4][NCH];
+        float pf[4];
+        u32 pb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int gi = g0 + j;
-          if (gi < ngroups) { // wave-uniform
-            int ri = gi * RPG + sub;
+          if (g0 + j < gend) { // wave-uniform
+            int ri = (g0 + j) * RPG + sub;
             if (ri > s_len - 1) ri = s_len - 1;
-            if (gi * RPG < L.SL)
+            if (STAGED || (g0 + j) * RPG < L.SL)
               load_row_lds<LPR, NCH>(L.stage + (size_t)ri * g.row_stride, t, g.n16, r[j]);
             else
               load_row<LPR, NCH>(g.rows + (size_t)L.s_ids[ri] * g.row_stride, t, g.n16, r[j]);
-          } else {
+          } else if (!STAGED) {
 #pragma unroll
             for (int k = 0; k < NCH; k++) r[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        // (fold4 never adds values of different rows: a staged pass of fewer than 4 groups skips the
+        // missing rows' reads and arithmetic instead of working on zeros)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          pf[j] = 0.f;
+          pb[j] = 0u;
+          if (!STAGED || g0 + j < gend) {
+            if (g.mclass == MC_BIN)
+              pb[j] = partial_bin<NCH>(c, r[j]);
+            else
+              pf[j] = partial_f32<NCH>(g.mclass, c, r[j]);
           }
         }
         const int myri = (g0 + j4) * RPG + sub;
@@ -2005,22 +2077,17 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
         const float rn = L.s_norm[on ? myri : 0];
         float d;
         if (g.mclass == MC_BIN)
-          d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
-                                              partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
-                           cn, rn);
+          d = finalize_bin(g, fold4<LPR, u32>(pb[0], pb[1], pb[2], pb[3]), cn, rn);
         else
-          d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
-                                                partial_f32<NCH>(g.mclass, c, r[1]),
-                                                partial_f32<NCH>(g.mclass, c, r[2]),
-                                                partial_f32<NCH>(g.mclass, c, r[3])),
-                           cn, rn);
+          d = finalize_f32(g, fold4<LPR, float>(pf[0], pf[1], pf[2], pf[3]), cn, rn);
         const float da = d * g.alpha; // hnsw.rs:585
         viol = __ballot(on && fbits(da) < cdb) != 0ull;
-        if (ln == 0) {
-          int done = ngroups - g0;
-          evals += (u64)(done < 4 ? done : 4) * RPG;
-        }
-      }
+        evals += (u64)((gend - g0) * RPG); // wave-uniform; lane 0's copy is the one that is added up
+      };
+      int g0 = 0;
+      for (; g0 < ngroups && !viol && (g0 + 4 < ngroups ? g0 + 4 : ngroups) * RPG <= L.SL; g0 += 4)
+        pass(g0, std::true_type{});
+      for (; g0 < ngroups && !viol; g0 += 4) pass(g0, std::false_type{});
     }
     const bool surv = have && !viol;
     if (ln == 0) {
@@ -2058,7 +2125,7 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
             if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << (q4 * 4 + j);
         }
       }
-      if (ln == 0) evals += (u64)w;
+      evals += (u64)w;
     }
     if (ln == 0) L.vmask[w] = vm;
     __syncthreads();
@@ -2117,8 +2184,11 @@ __device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL
   return L;
 }
 
+// rows up to 3 KB: 4 workgroups of 4 waves per CU is what the LDS carve allows, keep the registers there
+constexpr int wg_waves_per_simd(int nch, int nw) { return nw == 4 && nch <= 3 ? 4 : 1; }
+
 template <int LPR, int NCH, int NW, int SP>
-__global__ __launch_bounds__(NW * 64) void k_prune_wg(GraphDev g_in, PruneArgs a, int SL) {
+__global__ __launch_bounds__(NW * 64, wg_waves_per_simd(NCH, NW)) void k_prune_wg(GraphDev g_in, PruneArgs a, int SL) {
   GraphDev g = g_in;
   specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2385,7 +2455,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
 // add_link for the segments k_apply deferred (their list overflows): 256 threads per segment, the
 // self-prune runs on the LDS-staged wg_prune.
 template <int LPR, int NCH, int SP>
-__global__ __launch_bounds__(256) void k_apply_wg(GraphDev g_in, ApplyArgs a, int SL) {
+__global__ __launch_bounds__(256, wg_waves_per_simd(NCH, 4)) void k_apply_wg(GraphDev g_in, ApplyArgs a, int SL) {
   GraphDev g = g_in;
   specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -3171,6 +3241,44 @@ __global__ void k_iota_u64(u64 *p, u32 base, u32 n) {
 hipError_t hnyk_iota_u64(u64 *p, u32 base, u32 n, hipStream_t st) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(k_iota_u64, dim3((n + 255) / 256), dim3(256), 0, st, p, base, n);
+  return hipGetLastError();
+}
+
+// Device self-test of the cross-lane primitives above against __shfl_xor (one wave; bit i of out[lane]
+// = mismatch in check i).  hny_selftest_lane_ops, tests/test_gpu_parity.py.
+template <int OFF>
+__device__ __forceinline__ u32 lane_selftest_one(u32 v, u32 w) {
+  u32 bad = 0;
+  if (xshfl_u32<OFF>(v) != (u32)__shfl_xor((int)v, OFF, 64)) bad |= 1u;
+  const bool hi = (threadIdx.x & OFF) != 0;
+  {
+    const u32 keep = hi ? w : v, send = hi ? v : w;
+    if (fold_step<OFF, u32>(v, w) != keep + (u32)__shfl_xor((int)send, OFF, 64)) bad |= 2u;
+  }
+  {
+    const float a = __uint_as_float(0x3F800000u | (v & 0x7FFFFFu)), b = __uint_as_float(0x40000000u | (w & 0x7FFFFFu));
+    const float keep = hi ? b : a, send = hi ? a : b;
+    const float ref = keep + __shfl_xor(send, OFF, 64);
+    if (__float_as_uint(fold_step<OFF, float>(a, b)) != __float_as_uint(ref)) bad |= 4u;
+    if (__float_as_uint(xshfl<OFF>(a)) != __float_as_uint(__shfl_xor(a, OFF, 64))) bad |= 8u;
+  }
+  const u64 q = ((u64)v << 32) | w;
+  if (xshfl<OFF>(q) != (u64)__shfl_xor((long long)q, OFF, 64)) bad |= 16u;
+  return bad;
+}
+__global__ __launch_bounds__(64) void k_lane_selftest(u32 *out) {
+  const u32 v = (threadIdx.x + 1u) * 2654435761u, w = (threadIdx.x + 77u) * 40503u + 0x9E3779B9u;
+  u32 bad = 0;
+  bad |= lane_selftest_one<1>(v, w) << 0;
+  bad |= lane_selftest_one<2>(v, w) << 5;
+  bad |= lane_selftest_one<4>(v, w) << 10;
+  bad |= lane_selftest_one<8>(v, w) << 15;
+  bad |= lane_selftest_one<16>(v, w) << 20;
+  bad |= lane_selftest_one<32>(v, w) << 25;
+  out[threadIdx.x] = bad;
+}
+hipError_t hnyk_lane_selftest(u32 *out64, hipStream_t st) {
+  hipLaunchKernelGGL(k_lane_selftest, dim3(1), dim3(64), 0, st, out64);
   return hipGetLastError();
 }
 #endif // HNY_PART == 0

@@ -266,6 +266,13 @@ int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *ve
                        void *out_codes, void *out_headers);
 /* the same on the GPU (bulk ingest): bit codecs by ballot, Cosine norms in the reference's x86
  * summation order (simple_avx.rs / simple_sse.rs / scalar) — byte-identical to the host path */
+/* Diagnostic: runs the distance kernels' cross-lane primitives (DPP moves, v_permlane16/32_swap) next
+ * to the generic __shfl_xor on one wave of `device` (-1 = current).  HNY_OK when every lane agrees;
+ * HNY_ERR_DEVICE otherwise, with bit (5 * log2(offset) + check) of mismatch64[lane] set (may be
+ * NULL).  No reference counterpart: the reference's reductions are the AVX/SSE horizontal sums of
+ * src/spaces/simple_avx.rs:69-110. */
+int hny_selftest_lane_ops(int32_t device, uint32_t *mismatch64);
+
 int hny_encode_vectors_gpu(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
                            void *out_codes, void *out_headers, int32_t device);
 

@@ -1045,6 +1045,12 @@ def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
     _same_graph(gg2, og2)
 
 
+def test_cross_lane_primitives_match_shfl_xor(hny):
+    """xshfl<1..32> (DPP moves, v_permlane16/32_swap) and the swap-based fold steps == __shfl_xor on every
+    lane, for u32 / f32 / u64 payloads: the distance reductions keep the wave order bit for bit"""
+    assert hny.selftest_lane_ops() == [0] * 64
+
+
 @pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 4000, 64, 16, 96, 64), (1, 3000, 768, 16, 200, 100),
                                                    (3, 5000, 256, 8, 256, 48), (0, 2500, 20, 64, 128, 150),
                                                    (0, 3000, 32, 16, 768, 100),   # the fuzz pair, fuzz.rs:86-87
