@@ -1589,6 +1589,11 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   if (getenv("HNY_DEBUG_SUB"))
     fprintf(stderr, "[hny] sub-wave walks %llu, handed over %llu (visited table full %llu, tie pool full %llu)\n",
             stats[ST_SUB_DONE], stats[ST_SUB_RETRY], stats[ST_SUB_RETRY_VIS], stats[ST_SUB_RETRY_POOL]);
+#ifdef HNY_PHASE_CLOCKS
+  fprintf(stderr, "[hny] walk wave cycles: pop %llu list+visited %llu distances %llu insert %llu | expansions %llu | whole kernel %llu\n",
+          stats[ST_PH_POP], stats[ST_PH_LIST], stats[ST_PH_DIST], stats[ST_PH_INSERT], stats[ST_PH_EXPANSIONS],
+          stats[ST_PH_REST]);
+#endif
   if (getenv("HNY_DEBUG_COUNTS"))
     fprintf(stderr, "[hny] expansions %llu accepted %llu notfull %llu evals_walk %llu\n", stats[9], stats[10], stats[11],
             stats[ST_EVALS_WALK]);

@@ -38,7 +38,12 @@ enum {
   ST_SUB_RETRY = 13, // walks k_walk_sub handed over to k_walk
   ST_SUB_RETRY_VIS = 14,  // ... because the visited table filled up
   ST_SUB_RETRY_POOL = 15, // ... because the tie pool filled up
+#ifdef HNY_PHASE_CLOCKS // diagnostic build (HNY_CFLAGS=-DHNY_PHASE_CLOCKS): wave cycles per walk phase
+  ST_PH_POP = 16, ST_PH_LIST = 17, ST_PH_DIST = 18, ST_PH_INSERT = 19, ST_PH_EXPANSIONS = 20, ST_PH_REST = 21,
+  ST_COUNT = 24
+#else
   ST_COUNT = 16
+#endif
 };
 
 struct GraphDev {

@@ -646,7 +646,20 @@ struct Beam {
   u32 tie_bits;   // distance bits shared by the ordinary pool entries (== bits of res.max)
   bool dropped;   // some evicted ordinary candidate with bits > res.max is still in `candidates`
   u32 pool_over, err;
+#ifdef HNY_PHASE_CLOCKS
+  u64 ph[5], ph_t; // cycles in pop / list+visited / distances / insert, expansions; last stamp
+#endif
 };
+#ifdef HNY_PHASE_CLOCKS
+#define PH_STAMP(s, i)                                   \
+  do {                                                   \
+    const u64 now_ = __builtin_readcyclecounter();       \
+    (s).ph[i] += now_ - (s).ph_t;                        \
+    (s).ph_t = now_;                                     \
+  } while (0)
+#else
+#define PH_STAMP(s, i) do { } while (0)
+#endif
 
 // OrderedFloat orders by bit pattern (ordered_float.rs:25-29) while the two raw compares in
 // walk_layer (hnsw.rs:485, 505) use float order.  They disagree only for sign-bit-set or NaN
@@ -1075,6 +1088,10 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       if (iter > 200000u) err_iter = 1;
       break;
     }
+#ifdef HNY_PHASE_CLOCKS
+    s.ph_t = __builtin_readcyclecounter();
+    s.ph[4]++;
+#endif
     // ---- candidates.peek()/pop(): smallest distance bits, larger id first among equals
     // (BinaryHeap<(Reverse<OrderedFloat>, ItemId)>, :469, :483-488)
     int first_un = -1, last = -1;
@@ -1179,6 +1196,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #ifdef HNY_DEBUG_COUNTS
     if (ln == 0) atomicAdd(&g.stats[9], 1ull);
 #endif
+    PH_STAMP(s, 0);
 
     // ---- neighbours of c (:491-495): on-disk Links first (incremental builds, :438-441), then the
     // in-memory list
@@ -1194,7 +1212,10 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       bool valid = id != HNY_SENT;
       bool isnew = visited_insert(vis, id, valid);
       u64 nmask = __ballot(isnew);
-      if (!nmask) continue;
+      if (!nmask) {
+        PH_STAMP(s, 1);
+        continue;
+      }
       visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
       if (g.incremental) { // MissingKey => the item was deleted: visited, but never scored (:498-502)
         isnew = isnew && g.has_vec[id] != 0;
@@ -1223,10 +1244,12 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
       if (isnew) nb_ids[rank] = id;
       WSYNC();
+      PH_STAMP(s, 1);
       if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, n_new, nb_d); // :503
       else dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow);
       evals += (u64)n_new;
       WSYNC();
+      PH_STAMP(s, 2);
       const float myd = ln < n_new ? nb_d[ln] : 0.f;
       const u32 myid = ln < n_new ? nb_ids[ln] : 0u;
       int room = ef - s.res_len;
@@ -1257,6 +1280,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         if constexpr (RB) beam_insert_rb<RCN>(s, rb, ((u64)db << 32) | ((u64)idr << 1), ef);
         else beam_insert(s, ((u64)db << 32) | ((u64)idr << 1), ef);
       }
+      PH_STAMP(s, 3);
       } // pages of the list
     }
   }
@@ -1296,6 +1320,11 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   const int ln = threadIdx.x, t = ln % LPR;
 
   Beam s;
+#ifdef HNY_PHASE_CLOCKS
+  for (int i = 0; i < 5; i++) s.ph[i] = 0;
+  s.ph_t = 0;
+  const u64 ph_kernel_t0 = __builtin_readcyclecounter();
+#endif
   s.res = res;
   s.pool = pool;
   s.rcap = (int)a.rcap;
@@ -1485,6 +1514,16 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     if (vis.log_over) log_over_cnt++;
     visited_clear(vis);
   }
+#ifdef HNY_PHASE_CLOCKS
+  if (ln == 0) {
+    atomicAdd(&g.stats[ST_PH_POP], s.ph[0]);
+    atomicAdd(&g.stats[ST_PH_LIST], s.ph[1]);
+    atomicAdd(&g.stats[ST_PH_DIST], s.ph[2]);
+    atomicAdd(&g.stats[ST_PH_INSERT], s.ph[3]);
+    atomicAdd(&g.stats[ST_PH_EXPANSIONS], s.ph[4]);
+    atomicAdd(&g.stats[ST_PH_REST], __builtin_readcyclecounter() - ph_kernel_t0);
+  }
+#endif
   if (ln == 0) {
     if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
     if (s.pool_over) atomicAdd(&g.stats[ST_POOL_OVERFLOW], (u64)s.pool_over);
@@ -1687,6 +1726,10 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
   const int ln = threadIdx.x, t = ln % LPR;
 
   Beam s; // greedy descent through the upper layers: the ordinary (unfiltered) walk
+#ifdef HNY_PHASE_CLOCKS
+  for (int i = 0; i < 5; i++) s.ph[i] = 0;
+  s.ph_t = 0;
+#endif
   s.res = res;
   s.pool = pool;
   s.rcap = (int)a.rcap;
