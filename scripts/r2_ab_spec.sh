@@ -1,4 +1,4 @@
-# same-box A/B of the speculative neighbour-list fetch (HNY_SPEC_LIST=0/1): C5, 4M x 128, C2 walk seconds
+# same-box A/B of the speculative neighbour-list fetch (HNY_SPEC_LIST=0/1; the switch lived in the experiment only, DESIGN.md 5 "Short rows"): C5, 4M x 128, C2 walk seconds
 mkdir -p gpurun_out
 A="--no-cpu --no-recall --queries 0 --alt-data none --steps 2 --warmup 1"
 for cfg in "c5 --items 5000000 --dim 1024 --metric hamming --ef 64" "c4s --items 4000000 --dim 128" "c2"; do
