@@ -2019,7 +2019,7 @@ struct WgPruneLds {
   u64 *S;          // [HNY_MAX_CAP] selected keys
   u32 *s_ids;      // [HNY_MAX_CAP]
   float *s_norm;   // [HNY_MAX_CAP]
-  int *surv;       // [8] chunk member survived the test against S
+  int *surv;       // [2][8] chunk member survived the test against S (by chunk parity)
   u32 *vmask;      // [8] bit j: chunk member violates against chunk member j
   float *cnorm;    // [8]
   unsigned char *cbuf;  // [NW][row_stride] the chunk's candidate rows
@@ -2031,8 +2031,8 @@ struct WgPruneLds {
 // bits(dq)` does not depend on the order in which S is scanned, so NW consecutive candidates are
 // tested concurrently, one per wave, against the selected set as it stood before the chunk (rows
 // from LDS, early exit); the survivors are then tested against each other (rows exchanged through
-// LDS) and the chunk is resolved in candidate order — exactly the sequential outcome, with 3
-// barriers per NW candidates.  Each wave streams its next candidate row from HBM one chunk ahead.
+// LDS) and the chunk is resolved in candidate order — exactly the sequential outcome, with 1 to 3
+// barriers per NW candidates (see there).  Each wave streams its next candidate row from HBM one chunk ahead.
 template <int LPR, int NCH, int NW>
 __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int n, int cap, const WgPruneLds &L,
                                         u64 &evals) {
@@ -2133,55 +2133,69 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
       for (; g0 < ngroups && !viol; g0 += 4) pass(g0, std::false_type{});
     }
     const bool surv = have && !viol;
+    // Barriers: one per chunk when at most one candidate survived B and nothing is selected, a second
+    // only around the intra-chunk tests (two or more survivors), a third only when S changed.  The
+    // survivor flags alternate between two sets, so a wave that runs ahead into the next chunk never
+    // overwrites flags a slower wave is still reading (they meet again at that chunk's first barrier).
+    int *sv = L.surv + ((base / NW) & 1) * 8;
     if (ln == 0) {
-      L.surv[w] = surv ? 1 : 0;
+      sv[w] = surv ? 1 : 0;
       L.cnorm[w] = cn;
     }
     __syncthreads();
-    // C: survivors against the earlier members of the chunk (folded passes over cbuf, 4 rows each)
+    u32 svmask = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) svmask |= (sv[j] != 0 ? 1u : 0u) << j;
+    svmask = (u32)__builtin_amdgcn_readfirstlane((int)svmask);
+    const bool need_c = (svmask & (svmask - 1u)) != 0u; // two or more survivors
+    // C: survivors against the earlier survivors of the chunk (folded passes over cbuf, 4 rows each)
     u32 vm = 0;
-    if (surv && w > 0) {
+    if (need_c) {
+      if (surv && (svmask & ((1u << w) - 1u)) != 0u) {
 #pragma unroll
-      for (int q4 = 0; q4 < NW / 4; q4++) {
-        if (q4 * 4 < w) { // wave-uniform
-          float4 r[4][NCH];
+        for (int q4 = 0; q4 < NW / 4; q4++) {
+          if (q4 * 4 < w) { // wave-uniform
+            float4 r[4][NCH];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            load_row_lds<LPR, NCH>(L.cbuf + (size_t)(q4 * 4 + j) * g.row_stride, t, g.n16, r[j]);
-          const int jm = q4 * 4 + j4;
-          const float rn = L.cnorm[jm];
-          float d;
-          if (g.mclass == MC_BIN)
-            d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
-                                                partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
-                             cn, rn);
-          else
-            d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
-                                                  partial_f32<NCH>(g.mclass, c, r[1]),
-                                                  partial_f32<NCH>(g.mclass, c, r[2]),
-                                                  partial_f32<NCH>(g.mclass, c, r[3])),
-                             cn, rn);
-          const float da = d * g.alpha;
-          const bool hit = sub == 0 && jm < w && L.surv[jm] != 0 && fbits(da) < cdb;
+            for (int j = 0; j < 4; j++)
+              load_row_lds<LPR, NCH>(L.cbuf + (size_t)(q4 * 4 + j) * g.row_stride, t, g.n16, r[j]);
+            const int jm = q4 * 4 + j4;
+            const float rn = L.cnorm[jm];
+            float d;
+            if (g.mclass == MC_BIN)
+              d = finalize_bin(g, fold4<LPR, u32>(partial_bin<NCH>(c, r[0]), partial_bin<NCH>(c, r[1]),
+                                                  partial_bin<NCH>(c, r[2]), partial_bin<NCH>(c, r[3])),
+                               cn, rn);
+            else
+              d = finalize_f32(g, fold4<LPR, float>(partial_f32<NCH>(g.mclass, c, r[0]),
+                                                    partial_f32<NCH>(g.mclass, c, r[1]),
+                                                    partial_f32<NCH>(g.mclass, c, r[2]),
+                                                    partial_f32<NCH>(g.mclass, c, r[3])),
+                               cn, rn);
+            const float da = d * g.alpha;
+            const bool hit = sub == 0 && jm < w && ((svmask >> jm) & 1u) != 0u && fbits(da) < cdb;
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << (q4 * 4 + j);
+            for (int j = 0; j < 4; j++)
+              if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << (q4 * 4 + j);
+          }
         }
+        evals += (u64)w;
       }
-      evals += (u64)w;
+      if (ln == 0) L.vmask[w] = vm;
+      __syncthreads();
     }
-    if (ln == 0) L.vmask[w] = vm;
-    __syncthreads();
     // D: resolve the chunk in candidate order (every thread computes the same thing)
     u32 selmask = 0;
     int cnt = s_len;
 #pragma unroll
     for (int j = 0; j < NW; j++) {
-      if (cnt < cap && L.surv[j] != 0 && (L.vmask[j] & selmask) == 0u) { // :577-579, :583-592
+      const u32 vmj = need_c ? L.vmask[j] : 0u;
+      if (cnt < cap && ((svmask >> j) & 1u) != 0u && (vmj & selmask) == 0u) { // :577-579, :583-592
         selmask |= 1u << j;
         cnt++;
       }
     }
+    selmask = (u32)__builtin_amdgcn_readfirstlane((int)selmask);
     if ((selmask >> w) & 1u) {
       const int pos = s_len + __popc(selmask & ((1u << w) - 1u));
       if (ln == 0) {
@@ -2198,8 +2212,8 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
         }
       }
     }
-    s_len = cnt;
-    __syncthreads();
+    s_len = s_len + __popc(selmask);
+    if (selmask != 0u) __syncthreads(); // S changed: the next chunk's B reads it
   }
   return s_len;
 }
@@ -2210,7 +2224,7 @@ __host__ __device__ inline u32 wg_capmax(const GraphDev &g) {
   return (c + 63u) / 64u * 64u;
 }
 __host__ __device__ inline size_t wg_prune_lds_bytes(u32 rcap, u32 row_stride, int SL, int NW, u32 capmax) {
-  return (size_t)rcap * 8 + (size_t)capmax * (8 + 4 + 4) + 96 + (size_t)(SL + NW) * row_stride;
+  return (size_t)rcap * 8 + (size_t)capmax * (8 + 4 + 4) + 128 + (size_t)(SL + NW) * row_stride;
 }
 
 __device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL, u32 row_stride, int NW, u32 capmax) {
@@ -2219,7 +2233,7 @@ __device__ __forceinline__ WgPruneLds wg_prune_carve(unsigned char *base, int SL
   L.s_ids = reinterpret_cast<u32 *>(L.S + capmax);
   L.s_norm = reinterpret_cast<float *>(L.s_ids + capmax);
   L.surv = reinterpret_cast<int *>(L.s_norm + capmax);
-  L.vmask = reinterpret_cast<u32 *>(L.surv + 8);
+  L.vmask = reinterpret_cast<u32 *>(L.surv + 16);
   L.cnorm = reinterpret_cast<float *>(L.vmask + 8);
   L.cbuf = reinterpret_cast<unsigned char *>(L.cnorm + 8);
   L.stage = L.cbuf + (size_t)NW * row_stride;
