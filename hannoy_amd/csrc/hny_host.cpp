@@ -267,6 +267,10 @@ struct hny_builder {
       d_seg_start, d_nseg, d_deferred, d_deferred_b, d_fin_cnt0, d_fin_cntu, d_d0_ids, d_du_ids;
   DevBuf<unsigned char> d_has_vec, d_deleted;
   DevBuf<u64> d_old_recs, d_lkey_a, d_lkey_b, d_perm_a, d_perm_b;
+  // fill_gaps_from_deleted on lists of more than 64 slots (k_fill_gaps_wg): per-block scratch in HBM
+  DevBuf<u32> d_gap_bitmap, d_gap_bm;
+  DevBuf<u64> d_gap_keys, d_gap_sorted;
+  int gap_grid = 0;
   DevBuf<u32> d_eps0;
   // k_walk_sub (four queries per wave): per-query visited hash tables, the retry list and the work /
   // retry counters of a search call (3 words per walk launch)
@@ -623,12 +627,11 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   if (o.M == 0 || o.M0 < o.M) return fail(HNY_ERR_INVALID_ARG, "need 1 <= M <= M0");
   if (o.M > HNY_MAX_CAP) return fail(HNY_ERR_UNSUPPORTED, "M %u > %d", o.M, HNY_MAX_CAP);
   if (o.M0 > HNY_BIG_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_BIG_CAP);
-  // 64 < M0 <= 256: lists are walked 64 slots at a time and the workgroup kernels hold them whole;
-  // the one-wave kernels (incremental builds: fill_gaps_from_deleted; strict mode) keep one lane per slot
+  // 64 < M0 <= HNY_BIG_CAP: lists are walked 64 slots at a time and the workgroup kernels hold them
+  // whole (incremental builds: k_fill_gaps_wg); strict mode's one-wave kernels keep one lane per slot
   const bool bigcap = o.M0 > HNY_MAX_CAP;
-  if (bigcap && ((inc && !inc->load_only) || o.x86_order))
-    return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: fresh builds in the wave order only (no incremental build, no x86_order)",
-                o.M0, HNY_MAX_CAP);
+  if (bigcap && o.x86_order)
+    return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: builds in the wave order only (no x86_order)", o.M0, HNY_MAX_CAP);
   if (o.ef_construction == 0 || o.ef_construction > HNY_MAX_EF)
     return fail(HNY_ERR_UNSUPPORTED, "ef_construction %u outside [1, %d]", o.ef_construction,
                 HNY_MAX_EF);
@@ -1670,6 +1673,31 @@ int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **ou
 // record and bridge the holes deleted items leave
 static int run_fill_gaps(hny_builder *b) {
   if (!b->incremental || b->old_recs.empty()) return HNY_OK;
+  const u32 cap = std::max(b->g.M0, b->g.M);
+  if (cap > HNY_MAX_CAP) {
+    // wide lists: the workgroup kernel with its gathered set, scored list and bitmap in HBM
+    const u32 n_recs = (u32)b->old_recs.size();
+    const u32 capmax = (cap + 63u) / 64u * 64u;
+    const u32 words = (b->g.n + 31u) / 32u + 1u;
+    const u32 maxb = (u32)std::min<uint64_t>((uint64_t)b->g.n, (uint64_t)cap * (cap + 1u));
+    const size_t per_block = (size_t)words * 4 + (size_t)maxb * 4 + 2 * ((size_t)maxb + capmax) * 8;
+    if (!b->gap_grid) {
+      const size_t budget = (size_t)2 << 30;
+      int grid = (int)std::min<size_t>(std::max<size_t>(budget / per_block, 1), 1024);
+      b->gap_grid = grid;
+      HIP_TRY(b->d_gap_bitmap.alloc((size_t)grid * words));
+      HIP_TRY(b->d_gap_bm.alloc((size_t)grid * std::max<u32>(maxb, 1)));
+      HIP_TRY(b->d_gap_keys.alloc((size_t)grid * ((size_t)maxb + capmax)));
+      HIP_TRY(b->d_gap_sorted.alloc((size_t)grid * ((size_t)maxb + capmax)));
+      HIP_TRY(hipMemsetAsync(b->d_gap_bitmap.p, 0, (size_t)grid * words * 4, b->stream)); // the kernel leaves it zero
+    }
+    prof_begin(b, EV_APPLY);
+    HIP_TRY(hnyk_fill_gaps_wg(b->g, b->d_old_recs.p, n_recs, b->d_deleted.p, b->d_gap_bitmap.p, words, b->d_gap_bm.p,
+                              maxb, b->d_gap_keys.p, b->d_gap_sorted.p, b->stage_rows,
+                              (int)std::min<u32>(n_recs, (u32)b->gap_grid), b->shape, b->stream));
+    prof_end(b);
+    return HNY_OK;
+  }
   prof_begin(b, EV_APPLY);
   HIP_TRY(hnyk_fill_gaps(b->g, b->d_old_recs.p, (u32)b->old_recs.size(), b->d_deleted.p, b->shape,
                          b->stream));

@@ -244,6 +244,9 @@ hipError_t hnyk_pair_distances(const GraphDev &g, const u32 *a, const u32 *b, u3
                                LaunchShape s, hipStream_t st);
 hipError_t hnyk_fill_u32(u32 *p, u32 v, size_t n, hipStream_t st);
 // fill_gaps_from_deleted (hnsw.rs:334-415) for the old records rec[i] = layer << 31 | slot
+hipError_t hnyk_fill_gaps_wg(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
+                             u32 *bitmaps, u32 words, u32 *bm, u32 maxb, u64 *keys, u64 *sorted, int SL, int grid,
+                             LaunchShape s, hipStream_t st);
 hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
                           LaunchShape s, hipStream_t st);
 hipError_t hnyk_finalize_lists(u32 *ids, u32 *cnt_out, u32 n_lists, u32 cap, hipStream_t st);

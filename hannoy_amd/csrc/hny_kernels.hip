@@ -2786,6 +2786,176 @@ __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u
   }
 }
 
+// fill_gaps_from_deleted for lists of more than 64 slots (64 < M0 <= HNY_BIG_CAP), one 4-wave workgroup
+// per surviving old record.  Same outcome as k_fill_gaps; the one-lane-per-slot arrays become loops and
+// the gathered set lives in HBM: `bm` (= RoaringBitmap, ascending, no repeats) is built in a per-block
+// bitmap over the slots by atomicOr and read back word by word in ascending order (the touched word
+// range only; atomic exchange, which also clears it for the next record), the scored list is rank-sorted
+// in HBM and robust_prune is wg_prune with its candidate list there.  Sized for M0 = 768 on a small
+// index (the reference's fuzz test, src/tests/fuzz.rs:86-87); the bitmap read-back makes it O(n / 32)
+// per record, so large indexes belong to the M0 <= 64 kernel.
+__host__ __device__ inline size_t fill_gaps_wg_lds_bytes(u32 capmax, u32 row_stride, int SL) {
+  return (size_t)capmax * 8 + 256 * 8 + 64 + (size_t)capmax * (8 + 4 + 4) + 128 + (size_t)(SL + 4) * row_stride;
+}
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_fill_gaps_wg(GraphDev g, const u64 *recs, u32 n_recs,
+                                                      const unsigned char *deleted, u32 *bitmaps, u32 words,
+                                                      u32 *bm_all, u32 maxb, u64 *keys_all, u64 *sorted_all,
+                                                      int SL) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const u32 capmax = wg_capmax(g);
+  u32 *nl_ids = reinterpret_cast<u32 *>(smem);                 // [capmax] the record's in-memory list
+  float *nl_d = reinterpret_cast<float *>(nl_ids + capmax);    // [capmax]
+  u32 *wsc = reinterpret_cast<u32 *>(nl_d + capmax);           // [64] ids of a distance pass (+ slack)
+  float *wsd = reinterpret_cast<float *>(wsc + 256);           // [64]
+  int *misc = reinterpret_cast<int *>(wsd + 256);              // [0] first / [1] last touched word, [2..5] wave sums
+  WgPruneLds L = wg_prune_carve(reinterpret_cast<unsigned char *>(misc + 16), SL, g.row_stride, 4, capmax);
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, t = ln % LPR;
+  u32 *bitmap = bitmaps + (size_t)blockIdx.x * words;
+  u32 *bm = bm_all + (size_t)blockIdx.x * maxb;
+  u64 *keys = keys_all + (size_t)blockIdx.x * ((size_t)maxb + capmax);
+  u64 *sorted = sorted_all + (size_t)blockIdx.x * ((size_t)maxb + capmax);
+  u64 evals = 0;
+  for (u32 ri = blockIdx.x; ri < n_recs; ri += gridDim.x) {
+    const u64 rec = recs[ri];
+    const u32 layer = (u32)(rec >> 31), slot = (u32)(rec & 0x7FFFFFFFull);
+    u32 cap, dcap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)slot * g.M0;
+      dist = g.l0_dist + (size_t)slot * g.M0;
+      cntp = g.l0_cnt + slot;
+    } else {
+      size_t u = (size_t)g.upper_idx[slot] * g.up_layers + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    const int cnt = (int)(*cntp & 0xFFFFu);
+    for (int e = tid; e < cnt; e += 256) {
+      nl_ids[e] = ids[e];
+      nl_d[e] = dist[e];
+    }
+    if (tid == 0) {
+      misc[0] = 0x7FFFFFFF;
+      misc[1] = -1;
+    }
+    __syncthreads();
+    // ---- gather (:382-388): own old links + the old links of deleted old neighbours, minus deleted
+    const u32 *dl = disk_ids(g, layer, slot, dcap);
+    auto mark = [&](u32 y) {
+      if (y != HNY_SENT && deleted[y] == 0) {
+        atomicOr(&bitmap[y >> 5], 1u << (y & 31));
+        atomicMin(&misc[0], (int)(y >> 5));
+        atomicMax(&misc[1], (int)(y >> 5));
+      }
+    };
+    if (dl) {
+      for (u32 j = (u32)tid; j < dcap; j += 256u) mark(dl[j]);
+      for (u32 j = 0; j < dcap; j++) { // (block-uniform)
+        const u32 x = dl[j];
+        if (x == HNY_SENT) break;
+        if (deleted[x]) {
+          u32 c2;
+          const u32 *xl = disk_ids(g, layer, x, c2);
+          if (xl)
+            for (u32 t2 = (u32)tid; t2 < c2; t2 += 256u) mark(xl[t2]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- bm ascending: read the touched words back in order
+    const int wmin = misc[0], wmax = misc[1];
+    int nb = 0;
+    __syncthreads();
+    for (int w0 = wmin; w0 <= wmax; w0 += 256) {
+      const int wi = w0 + tid;
+      u32 bits = wi <= wmax ? __hip_atomic_exchange(&bitmap[wi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const int pc = __popc(bits);
+      int incl = pc; // inclusive scan inside the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (ln >= off) incl += o;
+      }
+      if (ln == 63) misc[2 + w] = incl;
+      __syncthreads();
+      int pos = nb + incl - pc;
+      for (int k = 0; k < w; k++) pos += misc[2 + k];
+      const int total = misc[2] + misc[3] + misc[4] + misc[5];
+      while (bits) {
+        const u32 b = (u32)__ffs((int)bits) - 1u;
+        bits &= bits - 1u;
+        if ((u32)pos < maxb) bm[pos] = (u32)wi * 32u + b;
+        pos++;
+      }
+      nb += total;
+      __syncthreads();
+    }
+    if ((u32)nb > maxb) nb = (int)maxb; // cannot happen: maxb = min(slots, cap * (cap + 1))
+    __syncthreads();
+    if (nb + cnt <= (int)cap) { // :391-400 distances are "no longer relevant": 0.0
+      for (int e = tid; e < nb; e += 256) {
+        ids[e] = bm[e];
+        dist[e] = 0.f;
+      }
+      for (int e = tid; e < cnt; e += 256) {
+        ids[nb + e] = nl_ids[e];
+        dist[nb + e] = nl_d[e];
+      }
+      if (tid == 0) *cntp = (u32)(nb + cnt);
+      __syncthreads();
+      continue;
+    }
+    // ---- :403-410 score the old links and prune old + new together
+    {
+      const unsigned char *qrow = g.rows + (size_t)slot * g.row_stride;
+      float4 q[NCH];
+      load_row<LPR, NCH>(qrow, t, g.n16, q);
+      const float qn = g.norms ? g.norms[slot] : 0.f;
+      for (int e = tid; e < cnt; e += 256) keys[e] = ((u64)fbits(nl_d[e]) << 32) | nl_ids[e];
+      // (dist_rows takes its lane from threadIdx.x: a one-wave routine, so wave 0 scores the set)
+      u32 *my_ids = wsc;
+      float *my_d = wsd;
+      if (w == 0)
+      for (int base = 0; base < nb; base += 64) {
+        const int c = nb - base < 64 ? nb - base : 64;
+        my_ids[ln] = ln < c ? bm[base + ln] : 0u;
+        WSYNC();
+        dist_rows<LPR, NCH>(g, q, qn, my_ids, c, my_d, qrow);
+        evals += (u64)c;
+        WSYNC();
+        if (ln < c) keys[cnt + base + ln] = ((u64)fbits(my_d[ln]) << 32) | my_ids[ln];
+        WSYNC();
+      }
+    }
+    __syncthreads();
+    const int n = cnt + nb;
+    for (int e = tid; e < n; e += 256) {
+      const u64 mine = keys[e];
+      int rk = 0;
+      for (int k2 = 0; k2 < n; k2++) {
+        const u64 o = keys[k2];
+        rk += (o < mine || (o == mine && k2 < e)) ? 1 : 0;
+      }
+      sorted[rk] = mine;
+    }
+    __syncthreads();
+    const int s_len = wg_prune<LPR, NCH, 4>(g, sorted, n, (int)cap, L, evals);
+    __syncthreads();
+    for (u32 e = (u32)tid; e < cap; e += 256u) {
+      const bool on = (int)e < s_len;
+      ids[e] = on ? (u32)(L.S[e] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[e] = on ? __uint_as_float((u32)(L.S[e] >> 32)) : 0.f;
+    }
+    if (tid == 0) *cntp = (u32)s_len;
+    __syncthreads();
+  }
+  if ((tid & 63) == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
+}
+
 // D::distance for explicit pairs of stored items (tests / parity checks)
 template <int LPR, int NCH>
 __global__ __launch_bounds__(64) void k_pair_distances(GraphDev g, const u32 *pa, const u32 *pb, u32 n,
@@ -3101,6 +3271,26 @@ struct GapsLauncher {
   }
 };
 template <int L, int C>
+struct GapsWgLauncher {
+  static hipError_t run(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
+                        u32 *bitmaps, u32 words, u32 *bm, u32 maxb, u64 *keys, u64 *sorted, int SL, int grid,
+                        hipStream_t st) {
+    if constexpr (C > 8) {
+      return hipErrorInvalidValue; // wg_prune: rows of at most 8 KB
+    } else {
+      const size_t lds = fill_gaps_wg_lds_bytes(wg_capmax(g), g.row_stride, SL);
+      if (lds > 65536) {
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_gaps_wg<L, C>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+      }
+      hipLaunchKernelGGL((k_fill_gaps_wg<L, C>), dim3(grid), dim3(256), lds, st, g, recs, n_recs, deleted, bitmaps,
+                         words, bm, maxb, keys, sorted, SL);
+      return hipGetLastError();
+    }
+  }
+};
+template <int L, int C>
 struct PairLauncher {
   static hipError_t run(const GraphDev &g, const u32 *a, const u32 *b, u32 n, float *out,
                         hipStream_t st) {
@@ -3211,6 +3401,13 @@ hipError_t hnyk_fill_gaps(const GraphDev &g, const u64 *recs, u32 n_recs, const 
                           LaunchShape s, hipStream_t st) {
   if (!n_recs) return hipSuccess;
   return dispatch_shape<GapsLauncher>(s, g, recs, n_recs, deleted, st);
+}
+hipError_t hnyk_fill_gaps_wg(const GraphDev &g, const u64 *recs, u32 n_recs, const unsigned char *deleted,
+                             u32 *bitmaps, u32 words, u32 *bm, u32 maxb, u64 *keys, u64 *sorted, int SL, int grid,
+                             LaunchShape s, hipStream_t st) {
+  if (!n_recs) return hipSuccess;
+  return dispatch_shape<GapsWgLauncher>(s, g, recs, n_recs, deleted, bitmaps, words, bm, maxb, keys, sorted, SL,
+                                        grid, st);
 }
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st) {
   u64 total = (u64)a.count * (a.batch_level + 1) * a.cap_sel;

@@ -52,14 +52,15 @@ typedef struct {
   int32_t metric;            /* hny_metric */
   uint32_t dim;              /* user dimensions (binary codecs pad to 64, binary.rs:80-94) */
   uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120).  1 <= M <= 64 and
-                              * M <= M0 <= 1024 for fresh builds in the wave order (and for loading /
-                              * searching a stored graph); M0 <= 64 for incremental builds and strict
-                              * mode, whose one-wave kernels keep one lane per neighbour slot.  That
-                              * covers every pair the reference's Python API offers ((4,8) .. (32,64),
-                              * python.rs:280) and a fresh build with the pair of the reference's fuzz
-                              * test, M = 16, M0 = 768 (src/tests/fuzz.rs:86-87).  OUT OF CONTRACT:
-                              * that test's INCREMENTAL builds on such lists, and anything wider —
-                              * HNY_ERR_UNSUPPORTED, never a silently different graph. */
+                              * M <= M0 <= 1024 in the wave order — fresh and incremental builds,
+                              * loading / searching a stored graph; M0 <= 64 in strict mode
+                              * (x86_order), whose one-wave kernels keep one lane per neighbour slot.
+                              * That covers every pair the reference's Python API offers ((4,8) ..
+                              * (32,64), python.rs:280) and the pair of the reference's fuzz test,
+                              * M = 16, M0 = 768 with incremental builds (src/tests/fuzz.rs:86-87,143).
+                              * Anything wider: HNY_ERR_UNSUPPORTED, never a silently different
+                              * graph.  (Incremental builds on lists of more than 64 slots read a
+                              * per-record bitmap over all slots back: meant for small indexes.) */
   uint32_t ef_construction;  /* default 100 (writer.rs:49) */
   float alpha;               /* default 1.0 (writer.rs:51) */
   uint64_t seed;             /* levels when items.levels == NULL: drawn exactly as the reference

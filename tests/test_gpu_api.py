@@ -88,9 +88,12 @@ def test_overwrite_and_delete_snapshots(H, kat):
     assert db.metadata(0)["entry_points"].tolist() == k4["entry_points"]
 
 
-def test_fuzz_invariants(H):
-    """src/tests/fuzz.rs:31-77: random add/del batches on 32-d Cosine; after every build all items
-    are findable (nns(1) of each stored vector returns itself) and no link points to a deleted item."""
+@pytest.mark.parametrize("M0", [32, 768])
+def test_fuzz_invariants(H, M0):
+    """src/tests/fuzz.rs:31-77, 83-143: random add/del batches on 32-d Cosine, M = 16, ef_construction 32,
+    incremental build after every batch; after every build all items are findable (nns(1) of each stored
+    vector returns itself) and no link points to a deleted item.  M0 = 768 is the reference's own pair
+    (fuzz.rs:86-87): lists of several hundred links, fill_gaps_from_deleted on them (k_fill_gaps_wg)."""
     rng = np.random.default_rng(42)
     dim = 32
     db = H.Database(None, H.Metric.COSINE)
@@ -106,7 +109,7 @@ def test_fuzz_invariants(H):
                 v = rng.uniform(-1, 1, dim).astype(np.float32)
                 w.add_item(i, v)
                 alive[i] = v
-        w.build()
+        w.build(M0=M0)
         ids = sorted(alive)
         assert db.metadata(0)["items"].tolist() == ids
         for item, layer, nb in _dump_links(db):
