@@ -128,6 +128,7 @@ struct WalkArgs {
   u32 *n_retry;
   const u32 *hi_dev; // k_walk: hi = lo + *hi_dev (null: hi as given)
   const u32 *cancel; // reader mode: pinned host word, non-zero = take no further query (reader.rs:333)
+  u32 xcd_tile;      // != 0: `queue` is 8 counters, one per XCD; tile k of xcd_tile members belongs to XCD k % 8
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,

@@ -1353,10 +1353,30 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   u32 err_iter = 0, log_over_cnt = 0;
 
   // dynamic work queue: queries differ a lot in length, a static stride leaves a long launch tail
+  u32 xq_dead = 0; // XCD-tiled queue: how many of the 8 counters this wave has found exhausted
   for (;;) {
     u32 m = 0;
     if (ln == 0) {
-      m = a.lo + atomicAdd(a.queue, 1u);
+      if (SP != 0 && !RM && a.xcd_tile) {
+        // Tiles of xcd_tile consecutive members (locality order) go round-robin to the 8 XCDs, each
+        // with its own counter: the waves of one XCD (= one L2) work on neighbouring queries while all
+        // eight stay inside the same window of the batch (= one Infinity-Cache footprint).  A wave
+        // whose XCD has run out helps the next one.
+        const u32 T = a.xcd_tile, cnt_all = a.hi - a.lo;
+        m = 0xFFFFFFFFu;
+        while (xq_dead < 8u) {
+          const u32 x = (blockIdx.x + xq_dead) & 7u;
+          const u32 c = atomicAdd(a.queue + x, 1u);
+          const u32 idx = ((c / T) * 8u + x) * T + (c % T);
+          if (idx < cnt_all) {
+            m = a.lo + idx;
+            break;
+          }
+          xq_dead++;
+        }
+      } else {
+        m = a.lo + atomicAdd(a.queue, 1u);
+      }
       if constexpr (RM || SP == 0) // the Visitor's cancel probe (reader.rs:333), between queries
         if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) m = 0xFFFFFFFFu;
     }

@@ -1048,6 +1048,25 @@ def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
     _same_graph(gg2, og2)
 
 
+@pytest.mark.parametrize("metric,n,dim,tile", [(0, 12000, 64, 16), (1, 12000, 256, 0), (3, 10000, 1024, 7)])
+def test_xcd_tiled_walk_queue_equals_oracle(orc, hny, monkeypatch, metric, n, dim, tile):
+    """the level-0 walks of a locality-ordered batch take their members from 8 per-XCD counters (tiles of
+    HNY_XCD_TILE consecutive members, stealing at the tail; default 512 for rows >= 1 KB, i.e. the
+    256-d case here with its 8 192-member batches): every member is still walked exactly once — graph
+    == oracle edge for edge, same walk evaluations"""
+    if tile:
+        monkeypatch.setenv("HNY_XCD_TILE", str(tile))
+    rng = np.random.default_rng(n + dim)
+    cent = rng.uniform(-1, 1, (16, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 16, n)] + 0.25 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, 16, seed=5))
+    kw = dict(batch_frac=1.0, batch_max=8192)
+    o = orc.build(ds, M=16, M0=32, ef=48, order=orc.ORDER_WAVE, threads=8, **kw)
+    g = hny.build(items, M=16, M0=32, ef_construction=48, **kw)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+
+
 def test_cross_lane_primitives_match_shfl_xor(hny):
     """xshfl<1..32> (DPP moves, v_permlane16/32_swap) and the swap-based fold steps == __shfl_xor on every
     lane, for u32 / f32 / u64 payloads: the distance reductions keep the wave order bit for bit"""
