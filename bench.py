@@ -201,6 +201,10 @@ def main():
              "bytes_per_eval": bytes_per_eval}
         if steps:  # the same bytes over the WHOLE step (prune, link ops, export included)
             r["frac_whole_build"] = round(wb / (dt_ / steps) / 1e9 / HBM_PEAK_GBS, 4)
+        if ach > HBM_PEAK_GBS:  # SURVEY 8(d)'s numerator counts every evaluated row, wherever it came from
+            r["note"] = ("achieved = algorithmic bytes / kernel time exceeds the HBM peak because part of the row "
+                         "reads are L2 hits (XCD-tiled work queue: neighbouring queries share an L2); "
+                         "l2_to_fabric_gbs is the counted L2->fabric traffic over the same time")
         return r
 
     def build_stats(g):
