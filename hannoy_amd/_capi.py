@@ -126,11 +126,14 @@ def load_library():
         import torch  # noqa: F401
     except Exception:
         pass
-    if not os.path.exists(LIB_PATH):
+    # HNY_LIB: another build of this same library (python -m hannoy_amd.buildlib --out PATH), for A/B
+    # measurements of two kernel variants on one box (scripts/r2_ab_lib.sh); still no CPU fallback
+    lib_path = os.environ.get("HNY_LIB") or LIB_PATH
+    if not os.path.exists(lib_path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m hannoy_amd.buildlib` "
+            f"{lib_path} is missing: build it with `python -m hannoy_amd.buildlib` "
             "(hipcc --offload-arch=gfx950). hannoy_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     vp = C.c_void_p
     L.hny_build.restype = C.c_int
     L.hny_build.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(C.POINTER(GraphStruct))]

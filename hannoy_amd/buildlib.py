@@ -37,12 +37,14 @@ def needs_build():
 KERNEL_PARTS = range(8)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, tag=""):
+    """out / tag: a second build of the library next to the regular one (objects get the tag in their
+    names), for same-box A/B runs through HNY_LIB"""
+    if out is None and not force and not needs_build():
         return LIB
     jobs = []
     for s in SOURCES:
-        stem = os.path.join(CSRC, os.path.splitext(s)[0])
+        stem = os.path.join(CSRC, os.path.splitext(s)[0] + tag)
         if s in HOST_ONLY:
             jobs.append((stem + ".o", [hipcc(), "-O2", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c",
                                        os.path.join(CSRC, s), "-o", stem + ".o"]))
@@ -64,13 +66,15 @@ def build(force=False, verbose=False):
     workers = max(1, min(len(jobs), int(os.environ.get("HNY_BUILD_JOBS", os.cpu_count() or 1))))
     with ThreadPoolExecutor(workers) as ex:
         objs = list(ex.map(run, jobs))
-    cmd = [hipcc(), "-shared", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lpthread"]
+    lib = out or LIB
+    cmd = [hipcc(), "-shared", "--offload-arch=gfx950", "-o", lib] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    o = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    build(force="--force" in sys.argv, verbose=True, out=o, tag="_ab" if o else "")
     print(LIB)
