@@ -1022,14 +1022,16 @@ def test_native_multi_gpu_driver_ranks_share_one_gpu(orc, hny, monkeypatch, worl
         hny.build(items, devices=[0] * world, cancel=lambda: len(seen) > 0, **kw)
 
 
-def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch):
+@pytest.mark.parametrize("M,M0", [(8, 16), (16, 96)])
+def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch, M, M0):
     """hny_build_incremental through the native driver (two ranks on one GPU): deletes + inserts on
-    top of a stored graph, fill_gaps_from_deleted on every replica, == oracle."""
+    top of a stored graph, fill_gaps_from_deleted on every replica (k_fill_gaps_wg for the wide lists
+    of the second case), == oracle."""
     monkeypatch.setenv("HNY_MGPU_SHIM", "1")
     monkeypatch.setenv("HNY_MGPU_VERIFY", "1")
     monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "16")
     rng = np.random.default_rng(5)
-    n, dim, M, M0, ef = 3000, 32, 8, 16, 40
+    n, dim, ef = 3000, 32, 40
     vecs = rng.uniform(-1, 1, (n + 600, dim)).astype(np.float32)
     kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=0.5, batch_max=512)
     kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=0.5, batch_max=512)
