@@ -846,7 +846,8 @@ def test_lds_visited_table_and_spill_equal_oracle(orc, hny, slots, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"HNY_OVERLAP": "1"}, {"HNY_PRUNE_NW": "8"}, {"HNY_NO_LOCALITY": "1"},
                                  {"HNY_STAGE_BYTES": "0"}, {"HNY_STAGE_BYTES": "8192", "HNY_PRUNE_NW": "8"},
-                                 {"HNY_NO_RB": "1"}, {"HNY_NO_FAST": "1"}])
+                                 {"HNY_NO_RB": "1"}, {"HNY_NO_FAST": "1"},
+                                 {"HNY_NO_FAST": "1", "HNY_PRUNE_NW": "8"}])  # 8-wave chunks exist in the general kernels only
 def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
     """Every measured-and-rejected variant that is still selectable by environment (DESIGN.md "what
     did not pay") must build the oracle's graph too: overlapped chunked prune, 8-wave prune chunks,
