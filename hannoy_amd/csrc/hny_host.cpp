@@ -283,6 +283,7 @@ struct hny_builder {
   DevBuf<unsigned char> d_sort_tmp;
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
+  uint64_t top_layer_nodes = 0; // see res_capacity
   int stage_rows = 0;      // selected rows staged in LDS by the workgroup prune kernels
   u32 cur_n_ops = 0, cur_n_def = 0; // of the batch being applied
   bool apply_open = false;          // between hny_builder_apply_begin and _merge
@@ -319,6 +320,25 @@ enum { EV_WALK = 0, EV_PRUNE = 1, EV_SORT = 2, EV_APPLY = 3, EV_KINDS = 4 };
 static uint32_t eps_cap_of(const hny_builder *b) {
   return (uint32_t)std::max<size_t>(64, (b->entry_points.size() + 63) / 64 * 64);
 }
+// Entries of a walk's result set (beam).  walk_layer pushes every entry point without a capacity check
+// (hnsw.rs:474-481) and only evicts when res.len() == ef (:505-512): a walk that starts from MORE entry
+// points than ef never evicts and keeps every point closer than its farthest entry point — up to all
+// items.  That happens when an index (or the batch of an incremental build that reset max_level to 0,
+// hnsw.rs:258-262) has drawn level 0 only.  Such a walk gets room for every item while the index is
+// small, 4x the entry points otherwise (at most 4 096 entries; beyond it the kernels report the
+// overflow, never a clipped result).
+// The same holds for the greedy descent (ef = 1) from several entry points: on the top layer it can
+// keep every node of that layer.  A fresh index has nothing but its entry points there; after an
+// update that lowered max_level (hnsw.rs:258-276) the layer also holds old nodes: `top_layer_nodes`.
+static uint32_t res_capacity(uint32_t ef, uint32_t n_eps, uint64_t n_slots, uint64_t top_layer_nodes) {
+  uint64_t need = (uint64_t)std::max(ef, n_eps) + 1;
+  if (n_eps > 1) need = std::max<uint64_t>(need, std::max<uint64_t>(top_layer_nodes, n_eps) + 1);
+  if (n_eps >= ef) need = n_slots + 1 <= 4096 ? n_slots + 1 : std::max<uint64_t>(4 * need, 1024);
+  uint32_t rcap = 64;
+  while (rcap < need && rcap < 4096u) rcap *= 2;
+  return rcap;
+}
+
 static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
   // measured: +5 % on 3 KB rows (C2/C3), -3 % on 512-B rows (the table clear per greedy layer and
   // the longer probes outweigh the saved L2 atomics when a row costs little; round 2, 5M x 1024 bits:
@@ -818,8 +838,12 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     return fail(HNY_ERR_UNSUPPORTED, "%zu entry points > %d", b->entry_points.size(), HNY_MAX_EPS);
 
   // ---- sizes ----
-  b->rcap = 64;
-  while (b->rcap < std::max<uint32_t>(o.ef_construction, (uint32_t)b->entry_points.size()) + 1) b->rcap *= 2;
+  b->top_layer_nodes = 0; // nodes a walk can meet on layer max_level: old records there + what gets inserted there
+  for (uint32_t s = 0; s < n; s++)
+    if ((((b->old_mask.empty() ? 0u : b->old_mask[s]) >> b->max_level) & 1u && !b->deleted[s]) ||
+        b->ins_level[s] >= (int8_t)b->max_level)
+      b->top_layer_nodes++;
+  b->rcap = res_capacity(o.ef_construction, (uint32_t)b->entry_points.size(), n, b->top_layer_nodes);
   b->max_batch = 1;
   b->max_ops = 2;
   b->sel_words = 2;
@@ -1869,8 +1893,7 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
                                 (u32)((size_t)b->n_upper * b->up_layers), b->o.M, b->stream));
     b->finalized = true;
   }
-  uint32_t rcap = 64;
-  while (rcap < std::max<uint32_t>(ef, (uint32_t)b->entry_points.size()) + 1) rcap *= 2;
+  const uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes);
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
   if (qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
   const uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
@@ -2038,8 +2061,7 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
                                 b->o.M, b->stream));
     b->finalized = true;
   }
-  uint32_t rcap = 64;
-  while (rcap < std::max<uint32_t>(ef, (uint32_t)b->entry_points.size()) + 1) rcap *= 2;
+  const uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes);
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
   if (!by_item && qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
   const uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);

@@ -1,0 +1,76 @@
+"""Random-configuration soak: fresh build + one incremental round (deletes, overwrites, additions) of
+random shapes — metric, dim, M, M0 up to several hundred, ef, schedule — GPU == oracle edge for edge.
+  python scripts/soak_random_configs.py [n_configs] [seed]     (on the MI355X box)"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hannoy_amd as hny
+from oracle import orc
+from conftest import draw_levels
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def same(g, o):
+    return (np.array_equal(g.rec_item, o.rec_item) and np.array_equal(g.rec_layer, o.rec_layer)
+            and np.array_equal(g.offsets, o.offsets) and np.array_equal(g.nbrs, o.nbrs)
+            and g.entry_points.tolist() == o.entry_points.tolist() and g.max_level == o.max_level
+            and g.n_evals_walk == o.n_evals_walk)
+
+
+t0 = time.time()
+for ci in range(n_cfg):
+    metric = int(rng.integers(0, 7))
+    dim = int(rng.choice([3, 20, 48, 100, 128, 300, 768, 1024]))
+    M = int(rng.choice([4, 8, 12, 16, 24, 32]))
+    M0 = int(rng.choice([M, 2 * M, 2 * M + 1, 70, 100, 200, 333, 768])) if rng.random() < 0.7 else 2 * M
+    M0 = max(M0, M)
+    n0 = int(rng.integers(400, 2500))
+    ef = int(rng.integers(16, 90))
+    frac = float(rng.choice([0.05, 0.25, 1.0]))
+    bmax = int(rng.choice([16, 256, 4096]))
+    clustered = rng.random() < 0.5
+    def vec(k):
+        if clustered:
+            return (cent[rng.integers(0, len(cent), k)] + 0.3 * rng.standard_normal((k, dim))).astype(np.float32)
+        return rng.uniform(-1, 1, (k, dim)).astype(np.float32)
+    cent = rng.uniform(-1, 1, (8, dim)).astype(np.float32)
+    vecs = {i: v for i, v in enumerate(vec(n0))}
+    kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax, threads=8)
+    kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+    tag = f"#{ci} metric {metric} dim {dim} M {M} M0 {M0} n {n0} ef {ef} frac {frac} bmax {bmax} {'clustered' if clustered else 'uniform'}"
+    print("run ", tag, flush=True)
+    def mk(levels):
+        ids = np.array(sorted(vecs), np.uint32)
+        mat = np.stack([vecs[int(i)] for i in ids])
+        return orc.Dataset.from_f32(metric, mat, levels if levels is not None else np.zeros(len(ids), np.uint8), ids)
+    ds = mk(draw_levels(n0, M, seed=ci))
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    og = orc.build(ds, **kw_o)
+    gg = hny.build(items, **kw_g)
+    ok1 = same(gg, og)
+    # one incremental round
+    alive = sorted(vecs)
+    to_delete = sorted(rng.choice(alive, max(1, n0 // 10), replace=False).tolist())
+    for i in to_delete:
+        del vecs[i]
+    alive = sorted(vecs)
+    overwrite = sorted(rng.choice(alive, max(1, n0 // 30), replace=False).tolist())
+    for i, v in zip(overwrite, vec(len(overwrite))):
+        vecs[i] = v
+    added = list(range(n0, n0 + n0 // 8))
+    for i, v in zip(added, vec(len(added))):
+        vecs[i] = v
+    to_insert = sorted(overwrite + added)
+    lv = draw_levels(len(to_insert), M, seed=100 + ci)
+    ds2 = mk(None)
+    items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, lv)
+    og2 = orc.build_incremental(ds2, og, to_insert, lv, to_delete, **{k: v for k, v in kw_o.items() if k != "threads"})
+    gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
+    ok2 = same(gg2, og2)
+    print(("ok  " if ok1 and ok2 else "FAIL"), tag, "fresh", ok1, "incremental", ok2, f"[{time.time() - t0:.0f} s]", flush=True)
+    assert ok1 and ok2, tag
+print("soak ok:", n_cfg, "configurations")

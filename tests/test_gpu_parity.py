@@ -342,6 +342,40 @@ def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac,
         assert {i for (i, l) in d if l == 0} == alive_set
 
 
+@pytest.mark.parametrize("new_level1", [0, 10])
+def test_incremental_more_entry_points_than_ef(orc, hny, new_level1):
+    """hnsw.rs:258-262: deleting an entry point usually resets max_level to 0, and when every item of the
+    update then draws level 0 ALL of them become entry points (:278-285).  walk_layer pushes entry points
+    without a capacity check and only evicts at len == ef (:474-481, :505-512), so with more entry
+    points than ef the result set keeps every point closer than its farthest entry point — hundreds here.
+    Found by scripts/soak_random_configs.py (the result set used to be sized max(ef, entry points) + 1
+    and the build stopped with HNY_ERR_DEVICE).  Second case: ten of the new items draw level 1, so
+    max_level becomes 1 (:272-276) with those ten as entry points — and the greedy descent (ef = 1) of
+    every level-0 item starts from ten entry points on a layer that still holds the ~80 old level-1
+    nodes.  GPU == oracle."""
+    rng = np.random.default_rng(11)
+    n, dim, M, M0, ef = 1300, 64, 16, 32, 45
+    vecs = rng.uniform(-1, 1, (n + 150, dim)).astype(np.float32)
+    kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=256)
+    kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=256)
+    ds, items = _mk(orc, hny, 6, vecs[:n], draw_levels(n, M, seed=4))
+    og = orc.build(ds, threads=8, **kw_o)
+    gg = hny.build(items, **kw_g)
+    _same_graph(gg, og)
+    to_delete = np.array(sorted(set(gg.entry_points.tolist()) | set(range(100, 140))), np.uint32)
+    alive = np.setdiff1d(np.arange(n + 150, dtype=np.uint32), to_delete)
+    to_insert = np.arange(n, n + 150, dtype=np.uint32)
+    lv = np.zeros(150, np.uint8)  # every new item on level 0 ...
+    lv[:new_level1] = 1            # ... or a few on level 1
+    ds2 = orc.Dataset.from_f32(6, vecs[alive], np.zeros(len(alive), np.uint8), alive)
+    items2 = hny.ItemSet(6, dim, ds2.ids, ds2.codes, ds2.headers, lv)
+    og2 = orc.build_incremental(ds2, og, to_insert, lv, to_delete, **kw_o)
+    gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
+    assert len(og2.entry_points) > (1 if new_level1 else ef)  # the scenario
+    _same_graph(gg2, og2)
+    assert gg2.n_evals_walk == og2.n_evals_walk
+
+
 @pytest.mark.parametrize("M,M0,keep_frac", [(16, 32, 0.05), (24, 48, 0.04), (32, 64, 0.5), (16, 96, 0.05)])
 def test_mass_deletion_fill_gaps_worst_case(orc, hny, M, M0, keep_frac):
     """fill_gaps_from_deleted (hnsw.rs:334-415) when most of the index is removed in one update: a
