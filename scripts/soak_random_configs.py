@@ -1,6 +1,8 @@
-"""Random-configuration soak: fresh build + one incremental round (deletes, overwrites, additions) of
-random shapes — metric, dim, M, M0 up to several hundred, ef, schedule — GPU == oracle edge for edge.
-  python scripts/soak_random_configs.py [n_configs] [seed]     (on the MI355X box)"""
+"""Random-configuration soak: fresh build + incremental rounds (deletes — now and then of the entry points —
+overwrites, additions) of random shapes — metric, dim, M, M0 up to several hundred, ef, schedule — GPU ==
+oracle edge for edge; after the last round the stored graph is loaded and searched (Reader::nns by vector,
+random k / ef_search, with and without a candidates filter) == the restated Reader.
+  python scripts/soak_random_configs.py [n_configs] [seed] [rounds]     (on the MI355X box)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +14,7 @@ from conftest import draw_levels
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 
 
 def same(g, o):
@@ -52,25 +55,54 @@ for ci in range(n_cfg):
     og = orc.build(ds, **kw_o)
     gg = hny.build(items, **kw_g)
     ok1 = same(gg, og)
-    # one incremental round
-    alive = sorted(vecs)
-    to_delete = sorted(rng.choice(alive, max(1, n0 // 10), replace=False).tolist())
-    for i in to_delete:
-        del vecs[i]
-    alive = sorted(vecs)
-    overwrite = sorted(rng.choice(alive, max(1, n0 // 30), replace=False).tolist())
-    for i, v in zip(overwrite, vec(len(overwrite))):
-        vecs[i] = v
-    added = list(range(n0, n0 + n0 // 8))
-    for i, v in zip(added, vec(len(added))):
-        vecs[i] = v
-    to_insert = sorted(overwrite + added)
-    lv = draw_levels(len(to_insert), M, seed=100 + ci)
-    ds2 = mk(None)
-    items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, lv)
-    og2 = orc.build_incremental(ds2, og, to_insert, lv, to_delete, **{k: v for k, v in kw_o.items() if k != "threads"})
-    gg2 = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
-    ok2 = same(gg2, og2)
+    # incremental rounds
+    ok2 = True
+    next_id = n0
+    for rnd in range(rounds):
+        alive = sorted(vecs)
+        to_delete = set(rng.choice(alive, max(1, len(alive) // 10), replace=False).tolist())
+        if rng.random() < 0.4:  # hnsw.rs:236-263: deleted entry points get replaced, max_level may reset
+            to_delete |= set(int(x) for x in gg.entry_points.tolist())
+        to_delete = sorted(to_delete & set(alive))
+        if len(to_delete) >= len(alive) - 2:
+            break
+        for i in to_delete:
+            del vecs[i]
+        alive = sorted(vecs)
+        overwrite = sorted(rng.choice(alive, max(1, len(alive) // 30), replace=False).tolist())
+        for i, v in zip(overwrite, vec(len(overwrite))):
+            vecs[i] = v
+        added = list(range(next_id, next_id + int(rng.integers(1, max(2, n0 // 6)))))
+        next_id = added[-1] + 1
+        for i, v in zip(added, vec(len(added))):
+            vecs[i] = v
+        to_insert = sorted(overwrite + added)
+        lv = draw_levels(len(to_insert), M, seed=100 * (rnd + 1) + ci)
+        if rng.random() < 0.3:
+            lv = np.zeros(len(to_insert), np.uint8)  # every new item on level 0 (hnsw.rs:278-285)
+        ds2 = mk(None)
+        items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, lv)
+        og = orc.build_incremental(ds2, og, to_insert, lv, to_delete, **{k: v for k, v in kw_o.items() if k != "threads"})
+        gg = hny.build_incremental(items2, gg, to_insert, to_delete, **kw_g)
+        ok2 = ok2 and same(gg, og)
+        ds = ds2
+    # search on the stored graph
+    nq = 64
+    qs = vec(nq)
+    qc = orc.encode_vectors(metric, qs)
+    qh = orc.make_headers(metric, dim, qc)
+    k = int(rng.integers(1, 20))
+    efs = int(rng.integers(1, 120))
+    items_s = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, np.zeros(0, np.uint8))
+    cand = np.sort(rng.choice(ds.ids, max(1, len(ds.ids) // int(rng.integers(2, 40))), replace=False)).astype(np.uint32)
+    with hny.Builder(items_s, prev=gg, load=True, M=M, M0=M0, ef_construction=ef) as b:
+        gi, gd, gc = b.search_knn(qc, qh, k=k, ef_search=efs)
+        fi, fd, fc = b.nns(qc, qh, k=k, ef_search=efs, candidates=cand)
+    oi, od, oc = orc.search(ds, gg, qc, qh, k=k, ef_search=efs, order=orc.ORDER_WAVE, threads=8)
+    ok3 = np.array_equal(oc, gc) and np.array_equal(oi, gi) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+    oi, od, oc = orc.search(ds, gg, qc, qh, k=k, ef_search=efs, order=orc.ORDER_WAVE, threads=8, candidates=cand)
+    ok3 = ok3 and np.array_equal(oc, fc) and np.array_equal(oi, fi)
+    ok2 = ok2 and ok3
     print(("ok  " if ok1 and ok2 else "FAIL"), tag, "fresh", ok1, "incremental", ok2, f"[{time.time() - t0:.0f} s]", flush=True)
     assert ok1 and ok2, tag
 print("soak ok:", n_cfg, "configurations")
