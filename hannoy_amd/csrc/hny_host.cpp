@@ -279,7 +279,7 @@ struct hny_builder {
   uint32_t sub_blocks = 0, vtab_slots = 0, ctr_used = 0;
   bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
-  DevBuf<u64> d_stats, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
+  DevBuf<u64> d_stats, d_stats_scratch, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
@@ -1461,7 +1461,19 @@ int hny_builder_sync(hny_builder *b) {
 static hipError_t clear_error_counters(hny_builder *b) {
   static_assert(ST_ERR_GAPS_OVERFLOW == ST_ERR_RES_OVERFLOW + 2 && ST_ERR_ITER == ST_ERR_RES_OVERFLOW + 1,
                 "error words are contiguous");
-  return hipMemsetAsync(b->d_stats.p + ST_ERR_RES_OVERFLOW, 0, 3 * sizeof(u64), b->stream);
+  hipError_t e = hipMemsetAsync(b->d_stats.p + ST_ERR_RES_OVERFLOW, 0, 3 * sizeof(u64), b->stream);
+  if (e != hipSuccess) return e;
+  return hipMemsetAsync(b->d_stats.p + ST_POOL_OVERFLOW, 0, sizeof(u64), b->stream);
+}
+// `candidates` entries that tie with the result set's maximum after being evicted from it stay poppable
+// in a 128-slot pool; more than that at once only happens when the distance takes a handful of values
+// (3-bit Hamming codes with lists of hundreds of links).  The dropped ones would make the graph differ
+// from the reference's without a trace, so the call fails instead.
+static int pool_overflow_error(hny_builder *b, unsigned long long n) {
+  (void)clear_error_counters(b);
+  return fail(HNY_ERR_DEVICE,
+              "tie pool overflow: %llu candidates that tie with the result set's maximum were dropped (more than %d "
+              "at once) — the graph would differ from the reference's", n, HNY_POOL_CAP);
 }
 
 void hny_graph_free(hny_graph *g) {
@@ -1491,6 +1503,7 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu gaps=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW]);
   }
+  if (stats[ST_POOL_OVERFLOW]) return pool_overflow_error(b, stats[ST_POOL_OVERFLOW]);
   // finalise every list on the device (sort + dedup), then copy through pinned staging
   const uint32_t upl = b->up_layers;
   const size_t nup = (size_t)b->n_upper * upl;
@@ -1757,6 +1770,31 @@ int hny_builder_load(const hny_build_opts *opts, const hny_items *items, const h
   return create_impl(opts, items, &inc, out);
 }
 
+// hny_multi.cpp: the distance-evaluation counters of a replica.  Work that every rank repeats (ramp-up
+// batches, small deferred sets, fill_gaps) is counted on rank 0 only: the other ranks point their kernels'
+// counter block at a scratch copy meanwhile (the error words in it are the same on every replica).
+extern "C" int hny_internal_builder_count_evals(hny_builder *b, int on) {
+  if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
+  HIP_TRY(hipSetDevice(b->device));
+  if (!on && !b->d_stats_scratch.p) {
+    HIP_TRY(b->d_stats_scratch.alloc(ST_COUNT));
+    HIP_TRY(hipMemsetAsync(b->d_stats_scratch.p, 0, ST_COUNT * 8, b->stream));
+  }
+  b->g.stats = on ? b->d_stats.p : b->d_stats_scratch.p;
+  return HNY_OK;
+}
+extern "C" int hny_internal_builder_read_evals(hny_builder *b, uint64_t out3[3]) {
+  if (!b || !out3) return fail(HNY_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  u64 stats[ST_COUNT] = {0};
+  HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  out3[0] = stats[ST_EVALS_WALK];
+  out3[1] = stats[ST_EVALS_PRUNE];
+  out3[2] = stats[ST_EVALS_APPLY];
+  return HNY_OK;
+}
+
 int hny_builder_fill_gaps(hny_builder *b) {
   if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
   if (b->pos < b->order.size() || b->in_batch) return fail(HNY_ERR_INVALID_ARG, "build not finished");
@@ -1999,6 +2037,7 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER]);
   }
+  if (stats[ST_POOL_OVERFLOW]) return pool_overflow_error(b, stats[ST_POOL_OVERFLOW]);
   return HNY_OK;
 }
 
@@ -2221,6 +2260,7 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu", stats[ST_ERR_RES_OVERFLOW],
                 stats[ST_ERR_ITER]);
   }
+  if (stats[ST_POOL_OVERFLOW]) return pool_overflow_error(b, stats[ST_POOL_OVERFLOW]);
   return HNY_OK;
 }
 

@@ -109,7 +109,8 @@ struct Shared {
   std::vector<int> rc;             // one slot per rank, combined by agree()
   std::vector<std::string> msg;
   std::vector<void *> buf;         // shim exchange: every rank's buffer of the current collective
-  explicit Shared(int w) : world(w), bar(w), rc(w, 0), msg(w), buf(w, nullptr) {}
+  std::vector<uint64_t> evals;     // [rank][walk, prune, apply]: summed into the graph rank 0 returns
+  explicit Shared(int w) : world(w), bar(w), rc(w, 0), msg(w), buf(w, nullptr), evals((size_t)w * 3, 0) {}
   // every rank posts its status; all of them get the first error (or 0).  Called before each
   // collective so that no rank waits inside one for a rank that has already failed.
   int agree(int rank, int my_rc) {
@@ -205,6 +206,9 @@ struct Job {
   const hny_prev_graph *prev; // null: fresh build
 };
 
+extern "C" int hny_internal_builder_count_evals(hny_builder *b, int on);
+extern "C" int hny_internal_builder_read_evals(hny_builder *b, uint64_t out3[3]);
+
 // the batch loop of one rank (hny_build's loop with the two exchanges in it)
 int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny_graph **out, uint64_t *checksum) {
   const int world = sh.world;
@@ -230,6 +234,8 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
   const uint32_t min_def = (uint32_t)std::max(1, env_int("HNY_MGPU_MIN_DEFERRED", 32 * world));
   const uint32_t xs = hny_builder_exch_stride_u64(b);
   uint64_t done = 0, total = 0;
+  // evaluation counters: what every rank repeats counts once (on rank 0), the shards add up
+  auto replicated = [&](bool yes) -> int { return rank ? hny_internal_builder_count_evals(b, yes ? 0 : 1) : 0; };
   for (;;) {
     int cancelled = 0;
     if (job.opts->cancel) { // polled by rank 0 before every batch, obeyed by all (lib.rs:140)
@@ -243,10 +249,13 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
     if (rc) return sh.agree(rank, rc);
     if (bt.count == 0) break;
     if (bt.count < min_shard) { // ramp-up: the exchange would cost more than the search
-      rc = hny_builder_search(b, 0, bt.count, nullptr);
+      rc = replicated(true);
+      if (!rc) rc = hny_builder_search(b, 0, bt.count, nullptr);
       if (!rc) rc = hny_builder_apply(b, nullptr);
       if (rc) return sh.agree(rank, rc);
     } else {
+      rc = replicated(false);
+      if (rc) return sh.agree(rank, rc);
       const uint32_t per = (bt.count + (uint32_t)world - 1) / (uint32_t)world;
       const uint32_t lo = std::min<uint32_t>((uint32_t)rank * per, bt.count), hi = std::min<uint32_t>(lo + per, bt.count);
       const size_t words = (size_t)world * per * bt.sel_stride_u64;
@@ -258,7 +267,8 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
       uint32_t nd = 0;
       if (!rc) rc = hny_builder_apply_begin(b, sel.p, &nd); // the same number on every rank
       if (!rc && nd < min_def) {
-        rc = hny_builder_apply_deferred(b, 0, 1, nullptr);
+        rc = replicated(true);
+        if (!rc) rc = hny_builder_apply_deferred(b, 0, 1, nullptr);
         if (!rc) rc = hny_builder_apply_merge(b, nullptr, 0, 1);
         if (rc) return sh.agree(rank, rc);
       } else {
@@ -279,10 +289,13 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
     }
   }
   if (job.prev) { // fill_gaps_from_deleted (hnsw.rs:187): deterministic, every replica does it
-    rc = hny_builder_fill_gaps(b);
+    rc = replicated(true);
+    if (!rc) rc = hny_builder_fill_gaps(b);
     if (rc) return sh.agree(rank, rc);
   }
-  rc = sh.agree(rank, 0);
+  rc = replicated(false);
+  if (!rc) rc = hny_internal_builder_read_evals(b, &sh.evals[(size_t)rank * 3]);
+  rc = sh.agree(rank, rc);
   if (rc) return rc;
   const bool verify = env_int("HNY_MGPU_VERIFY", 0) != 0;
   if (rank == 0 || verify) {
@@ -295,10 +308,17 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
       for (uint64_t i = 0; i <= g->n_records; i++) h = (h ^ g->rec_offset[i]) * 1099511628211ull;
       *checksum = h;
     }
-    if (rank == 0 && !rc)
+    if (rank == 0 && !rc) {
+      for (int r = 1; r < world; r++) { // the other ranks' shards of the sharded work
+        g->n_evals_walk += sh.evals[(size_t)r * 3 + 0];
+        g->n_evals_prune += sh.evals[(size_t)r * 3 + 1];
+        g->n_evals_apply += sh.evals[(size_t)r * 3 + 2];
+        g->n_distance_evals += sh.evals[(size_t)r * 3 + 0] + sh.evals[(size_t)r * 3 + 1] + sh.evals[(size_t)r * 3 + 2];
+      }
       *out = g;
-    else
+    } else {
       hny_graph_free(g);
+    }
   } else {
     rc = hny_builder_sync(b);
   }

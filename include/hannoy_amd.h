@@ -119,7 +119,8 @@ typedef struct {
   uint64_t n_evals_walk, n_evals_prune, n_evals_apply;
   uint64_t n_batches;
   double t_upload_s, t_build_s, t_export_s; /* host wall clock of the three phases */
-  uint64_t n_tie_pool_overflow; /* exactness counter, 0 in every supported case */
+  uint64_t n_tie_pool_overflow; /* always 0 in a returned graph: an overflow of the walk's tie pool fails
+                                 * the call with HNY_ERR_DEVICE */
   /* device time per kernel family, from HIP events on the build stream; filled only after
    * hny_builder_set_profiling(b, 1) (else 0) */
   double t_walk_kernels_s, t_prune_kernels_s, t_sort_kernels_s, t_apply_kernels_s;

@@ -1104,6 +1104,33 @@ def test_xcd_tiled_walk_queue_equals_oracle(orc, hny, monkeypatch, metric, n, di
     assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
+def test_tie_pool_overflow_fails_loudly(orc, hny):
+    """Found by scripts/soak_random_configs.py: 3-bit Hamming codes (four distinct distances) and M0 = 333 —
+    hundreds of evicted candidates tie with the result set's maximum at once, more than the walk's
+    128-slot tie pool holds.  Dropping them used to be visible in `n_tie_pool_overflow` only, and an
+    update of this index came out with 46 records different from the oracle's; now the call fails with
+    HNY_ERR_DEVICE.  With M0 = 64 the same data builds and updates exactly."""
+    h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
+    metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
+    frac = float(h["frac"][0])
+    ds = orc.Dataset.from_f32(metric, h["mat0"], h["lv0"], h["ids0"])
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+    assert e.value.code == -7 and "tie pool overflow" in str(e.value)
+    kw_o = dict(M=M, M0=64, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax)
+    kw_g = dict(M=M, M0=64, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+    og = orc.build(ds, threads=8, **kw_o)
+    gg = hny.build(items, **kw_g)
+    _same_graph(gg, og)
+    ds2 = orc.Dataset.from_f32(metric, h["mat1"], np.zeros(len(h["ids1"]), np.uint8), h["ids1"])
+    items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, h["lv1"])
+    og2 = orc.build_incremental(ds2, og, h["ins1"], h["lv1"], h["del1"], **kw_o)
+    gg2 = hny.build_incremental(items2, gg, h["ins1"], h["del1"], **kw_g)
+    _same_graph(gg2, og2)
+    assert gg2.n_tie_pool_overflow == 0
+
+
 def test_cross_lane_primitives_match_shfl_xor(hny):
     """xshfl<1..32> (DPP moves, v_permlane16/32_swap) and the swap-based fold steps == __shfl_xor on every
     lane, for u32 / f32 / u64 payloads: the distance reductions keep the wave order bit for bit"""
@@ -1160,6 +1187,10 @@ def test_m0_beyond_64_native_multi_gpu(orc, hny, monkeypatch):
     o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
     g = hny.build(items, M=M, M0=M0, ef_construction=ef, devices=[0, 0, 0], **kw)
     _same_graph(g, o)
+    g1 = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    # the counters of the three ranks add up to the one-GPU build's (replicated work counted once)
+    assert (g.n_evals_walk, g.n_evals_prune, g.n_evals_apply) == (g1.n_evals_walk, g1.n_evals_prune, g1.n_evals_apply)
+    assert g.n_evals_walk == o.n_evals_walk and g.n_distance_evals == g1.n_distance_evals
 
 
 def test_m0_limits_are_refused_loudly(orc, hny):
