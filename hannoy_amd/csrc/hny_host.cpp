@@ -1500,8 +1500,10 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
   if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER] || stats[ST_ERR_GAPS_OVERFLOW]) {
     (void)clear_error_counters(b); // reported once: a later reset / search starts clean
-    return fail(HNY_ERR_DEVICE, "kernel overflow: res=%llu iter=%llu gaps=%llu", stats[ST_ERR_RES_OVERFLOW],
-                stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW]);
+    return fail(HNY_ERR_DEVICE,
+                "kernel overflow: res=%llu iter=%llu gaps=%llu (res: a walk's result set outgrew its %u entries — a walk "
+                "that starts from more entry points than its ef keeps every closer point, see res_capacity / DESIGN.md limits)",
+                stats[ST_ERR_RES_OVERFLOW], stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW], b->rcap);
   }
   if (stats[ST_POOL_OVERFLOW]) return pool_overflow_error(b, stats[ST_POOL_OVERFLOW]);
   // finalise every list on the device (sort + dedup), then copy through pinned staging
