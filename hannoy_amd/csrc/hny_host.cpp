@@ -279,7 +279,7 @@ struct hny_builder {
   uint32_t sub_blocks = 0, vtab_slots = 0, ctr_used = 0;
   bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
-  DevBuf<u64> d_stats, d_stats_scratch, d_sel, d_cand, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
+  DevBuf<u64> d_stats, d_stats_scratch, d_sel, d_cand, d_res_global, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
@@ -330,12 +330,17 @@ static uint32_t eps_cap_of(const hny_builder *b) {
 // The same holds for the greedy descent (ef = 1) from several entry points: on the top layer it can
 // keep every node of that layer.  A fresh index has nothing but its entry points there; after an
 // update that lowered max_level (hnsw.rs:258-276) the layer also holds old nodes: `top_layer_nodes`.
-static uint32_t res_capacity(uint32_t ef, uint32_t n_eps, uint64_t n_slots, uint64_t top_layer_nodes) {
+// `cap`: 4 096 entries fit the walk's LDS (the Reader's searches stop there); the build takes up to
+// HNY_RES_GLOBAL_MAX with the result sets in HBM (WalkArgs.res_global, the general kernels).
+#define HNY_RES_LDS_MAX 4096u
+#define HNY_RES_GLOBAL_MAX 65536u
+static uint32_t res_capacity(uint32_t ef, uint32_t n_eps, uint64_t n_slots, uint64_t top_layer_nodes,
+                             uint32_t cap = HNY_RES_LDS_MAX) {
   uint64_t need = (uint64_t)std::max(ef, n_eps) + 1;
   if (n_eps > 1) need = std::max<uint64_t>(need, std::max<uint64_t>(top_layer_nodes, n_eps) + 1);
-  if (n_eps >= ef) need = n_slots + 1 <= 4096 ? n_slots + 1 : std::max<uint64_t>(4 * need, 1024);
+  if (n_eps >= ef) need = n_slots + 1 <= cap ? n_slots + 1 : std::max<uint64_t>(4 * need, 1024);
   uint32_t rcap = 64;
-  while (rcap < need && rcap < 4096u) rcap *= 2;
+  while (rcap < need && rcap < cap) rcap *= 2;
   return rcap;
 }
 
@@ -843,7 +848,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     if ((((b->old_mask.empty() ? 0u : b->old_mask[s]) >> b->max_level) & 1u && !b->deleted[s]) ||
         b->ins_level[s] >= (int8_t)b->max_level)
       b->top_layer_nodes++;
-  b->rcap = res_capacity(o.ef_construction, (uint32_t)b->entry_points.size(), n, b->top_layer_nodes);
+  b->rcap = res_capacity(o.ef_construction, (uint32_t)b->entry_points.size(), n, b->top_layer_nodes, HNY_RES_GLOBAL_MAX);
   b->max_batch = 1;
   b->max_ops = 2;
   b->sel_words = 2;
@@ -929,6 +934,14 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_vlog.alloc((size_t)slots * b->log_cap));
   HIP_TRY(b->d_sel.alloc(b->sel_words));
   const size_t cand_rows = std::max<uint32_t>(b->max_batch, 256);
+  if (b->rcap > HNY_RES_LDS_MAX) { // walks that never evict (res_capacity): result sets and candidate lists in HBM
+    if (b->wave_prune_only)
+      return fail(HNY_ERR_UNSUPPORTED, "a result set of %u entries needs the workgroup prune kernels (no x86_order, rows <= 8 KB)", b->rcap);
+    if ((cand_rows + slots) * (size_t)b->rcap * 8 > ((size_t)24 << 30))
+      return fail(HNY_ERR_UNSUPPORTED, "result sets of %u entries for %zu batch members exceed the 24 GB set aside for them; "
+                  "pass a smaller batch_max", b->rcap, cand_rows);
+    HIP_TRY(b->d_res_global.alloc((size_t)slots * b->rcap));
+  }
   HIP_TRY(b->d_cand.alloc(cand_rows * b->rcap));
   HIP_TRY(b->d_cand_n.alloc(cand_rows));
   HIP_TRY(b->d_keys_a.alloc(b->max_ops));
@@ -1160,9 +1173,10 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
-    w.vis_slots = vis_slots_for(b, w.rcap);
+    w.vis_slots = vis_slots_for(b, b->d_res_global.p ? 0u : w.rcap);
     w.eps_cap = eps_cap_of(b);
     w.queue = queue;
+    w.res_global = b->d_res_global.p; // null unless the result sets outgrow the LDS (res_capacity)
     return w;
   };
   auto prune_args = [&](int32_t l, uint32_t clo, uint32_t chi) {
@@ -1179,6 +1193,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     p.sel_stride = b->cur.sel_stride_u64;
     p.cap_sel = cs;
     p.batch_level = L;
+    p.list_global = b->rcap > HNY_RES_LDS_MAX ? 1u : 0u;
     return p;
   };
   auto launch_prune = [&](const PruneArgs &p, hipStream_t st) -> hipError_t {
@@ -1933,14 +1948,18 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
                                 (u32)((size_t)b->n_upper * b->up_layers), b->o.M, b->stream));
     b->finalized = true;
   }
-  const uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes);
+  const uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes, HNY_RES_GLOBAL_MAX);
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
   if (qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
-  const uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
+  uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
   DevBuf<unsigned char> dq;
   DevBuf<float> dqn;
-  DevBuf<u64> dcand;
+  DevBuf<u64> dcand, dres; // dres: result sets beyond the LDS (a search from more entry points than ef, res_capacity)
   DevBuf<u32> dcn;
+  if (rcap > HNY_RES_LDS_MAX) {
+    chunk = std::min<uint32_t>(chunk, 4096);
+    HIP_TRY(dres.alloc((size_t)std::min<uint32_t>(chunk, b->walk_slots) * rcap));
+  }
   HIP_TRY(dq.alloc((size_t)chunk * b->g.row_stride));
   HIP_TRY(dqn.alloc(chunk));
   HIP_TRY(dcand.alloc((size_t)chunk * rcap));
@@ -1986,7 +2005,8 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.bits_words = b->bits_words;
     w.vlog = b->d_vlog.p;
     w.log_cap = b->log_cap;
-    w.vis_slots = vis_slots_for(b, w.rcap);
+    w.res_global = dres.p;
+    w.vis_slots = vis_slots_for(b, dres.p ? 0u : w.rcap);
     w.eps_cap = eps_cap_of(b);
     w.queue = queues;
     w.cancel = sc.d;

@@ -128,6 +128,7 @@ struct WalkArgs {
   u32 *n_retry;
   const u32 *hi_dev; // k_walk: hi = lo + *hi_dev (null: hi as given)
   const u32 *cancel; // reader mode: pinned host word, non-zero = take no further query (reader.rs:333)
+  u64 *res_global;   // general kernels: result sets of more than 4 096 entries live in HBM, [grid][rcap] (else null: LDS)
   u32 xcd_tile;      // != 0: `queue` is 8 counters, one per XCD; tile k of xcd_tile members belongs to XCD k % 8
 };
 
@@ -178,6 +179,7 @@ struct PruneArgs {
   u64 *sel;
   u32 sel_stride, cap_sel, batch_level;
   const u64 *perm;  // processing order (index -> member), or null
+  u32 list_global;  // general kernels: candidate lists too long for LDS are pruned straight from `cand`
 };
 
 struct EmitArgs {

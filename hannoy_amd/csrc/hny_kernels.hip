@@ -1314,6 +1314,14 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
+  if constexpr (SP == 0) {
+    // a result set of more than 4 096 entries (a walk that never evicts, res_capacity in hny_host.cpp)
+    // lives in HBM: the beam code only sees a pointer, WSYNC fences every address space
+    if (a.res_global) {
+      pool = res;
+      res = a.res_global + (size_t)blockIdx.x * a.rcap;
+    }
+  }
   u32 *nb_ids = reinterpret_cast<u32 *>(pool + HNY_POOL_CAP);
   float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
   u32 *eps = reinterpret_cast<u32 *>(nb_d + 64);
@@ -2270,13 +2278,18 @@ __global__ __launch_bounds__(NW * 64, wg_waves_per_simd(NCH, NW)) void k_prune_w
   specialize<SP>(g);
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *list = reinterpret_cast<u64 *>(smem);
-  WgPruneLds L = wg_prune_carve(smem + (size_t)a.rcap * 8, SL, g.row_stride, NW, wg_capmax(g));
+  const bool list_global = SP == 0 && a.list_global != 0; // lists too long for LDS: pruned straight from HBM
+  WgPruneLds L = wg_prune_carve(smem + (list_global ? (size_t)0 : (size_t)a.rcap * 8), SL, g.row_stride, NW, wg_capmax(g));
   const int tid = threadIdx.x;
   u64 evals = 0;
   for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
     const u32 m = a.perm ? (u32)a.perm[mi - a.lo] : mi; // same locality order as the walk
     const int n = (int)a.cand_n[m];
-    for (int e = tid; e < n; e += blockDim.x) list[e] = a.cand[(size_t)m * a.rcap + e];
+    if (list_global) {
+      list = const_cast<u64 *>(a.cand) + (size_t)m * a.rcap;
+    } else {
+      for (int e = tid; e < n; e += blockDim.x) list[e] = a.cand[(size_t)m * a.rcap + e];
+    }
     __syncthreads();
     int s_len;
     if constexpr (SP != 0) {
@@ -3147,7 +3160,7 @@ struct Hot {
   template <int L, int C>
   struct Walk {
     static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
-      size_t lds = hnyk_walk_lds_bytes(a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
+      size_t lds = hnyk_walk_lds_bytes(a.res_global ? 0u : a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
       if constexpr (SP == 0) {
         if (a.eps_cap > 64) {
           hipLaunchKernelGGL((k_walk<L, C, true, 0>), dim3(grid), dim3(64), lds, st, g, a);
@@ -3207,7 +3220,7 @@ struct Hot {
       if constexpr (C > 8) {
         return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
       } else {
-        size_t lds = wg_prune_lds_bytes(a.rcap, g.row_stride, SL, nw, wg_capmax(g));
+        size_t lds = wg_prune_lds_bytes((SP == 0 && a.list_global) ? 0u : a.rcap, g.row_stride, SL, nw, wg_capmax(g));
         if constexpr (SP == 0) {
           if (nw == 8) {
             hipLaunchKernelGGL((k_prune_wg<L, C, 8, 0>), dim3(grid), dim3(512), lds, st, g, a, SL);
@@ -3372,7 +3385,7 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap) {
 }
 
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
-  if (fast_path(g) && a.eps_cap <= 64) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
+  if (fast_path(g) && a.eps_cap <= 64 && !a.res_global) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
   return dispatch_shape<Hot<0>::Walk>(s, g, a, grid, st);
 }
 int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s) {
@@ -3405,7 +3418,7 @@ hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int 
 }
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st) {
-  if (fast_path(g) && nw == 4) { HNY_SP_SWITCH(hnyk_prune_wg_sp, g, a, s, SL, nw, grid, st) }
+  if (fast_path(g) && nw == 4 && !a.list_global) { HNY_SP_SWITCH(hnyk_prune_wg_sp, g, a, s, SL, nw, grid, st) }
   return dispatch_shape<Hot<0>::PruneWg>(s, g, a, SL, nw, grid, st);
 }
 hipError_t hnyk_apply_wg(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,

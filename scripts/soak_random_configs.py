@@ -135,7 +135,7 @@ for ci in range(n_cfg):
       assert ok1 and ok2, tag
   except hny.HannoyError as e:
     # inside the contract: degenerate ties overflow the walk's tie pool / a result set beyond 4 096 entries — refused loudly
-    if e.code == -7 and ("tie pool overflow" in str(e) or "kernel overflow: res" in str(e)):
+    if (e.code == -7 and ("tie pool overflow" in str(e) or "kernel overflow: res" in str(e))) or (e.code == -5 and "entry points >" in str(e)):
         refused += 1
         print("refused", tag, "--", str(e)[:90], flush=True)
     else:

@@ -342,8 +342,8 @@ def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac,
         assert {i for (i, l) in d if l == 0} == alive_set
 
 
-@pytest.mark.parametrize("new_level1", [0, 10])
-def test_incremental_more_entry_points_than_ef(orc, hny, new_level1):
+@pytest.mark.parametrize("n,new_level1", [(1300, 0), (1300, 10), (6000, 0), (9000, 10)])
+def test_incremental_more_entry_points_than_ef(orc, hny, n, new_level1):
     """hnsw.rs:258-262: deleting an entry point usually resets max_level to 0, and when every item of the
     update then draws level 0 ALL of them become entry points (:278-285).  walk_layer pushes entry points
     without a capacity check and only evicts at len == ef (:474-481, :505-512), so with more entry
@@ -354,7 +354,7 @@ def test_incremental_more_entry_points_than_ef(orc, hny, new_level1):
     every level-0 item starts from ten entry points on a layer that still holds the ~80 old level-1
     nodes.  GPU == oracle."""
     rng = np.random.default_rng(11)
-    n, dim, M, M0, ef = 1300, 64, 16, 32, 45
+    dim, M, M0, ef = 64, 16, 32, 45  # (n > 4 096: the result sets no longer fit the LDS and live in HBM)
     vecs = rng.uniform(-1, 1, (n + 150, dim)).astype(np.float32)
     kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=256)
     kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=256)
