@@ -43,7 +43,11 @@ enum {
   HNY_ERR_INVALID_DIM = -4,      /* Error::InvalidVecDimension, error.rs:19-26 (stride/dim mismatch) */
   HNY_ERR_UNSUPPORTED = -5,      /* dim / M0 / ef beyond what the kernels are built for */
   HNY_ERR_NO_DEVICE = -6,        /* no usable gfx950 device / HIP failure */
-  HNY_ERR_DEVICE = -7,           /* a kernel reported an internal overflow (see hny_last_error) */
+  HNY_ERR_DEVICE = -7,           /* a kernel reported an internal overflow (see hny_last_error): the result
+                                  * set of a walk that never evicts outgrew 65 536 entries (4 096 in a
+                                  * filtered search), or more than 128 candidates tied with the result
+                                  * set's maximum at once (tie pool) — inputs the reference still handles,
+                                  * slowly; nothing has been written, the call can be repeated on the CPU */
   HNY_ERR_OOM = -8
 };
 
