@@ -2029,6 +2029,13 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
       w.eps_in = b->d_eps0.p;
       w.perm = b->d_perm_b.p;
       w.queue = queues + 1;
+      // the same XCD-tiled work queue as the build's level-0 walks (rows >= 1 KB, see run_batch)
+      const u32 xcd_tile = (u32)std::max(0, env_int("HNY_XCD_TILE", b->g.row_stride >= 1024u ? 512 : 0));
+      if (xcd_tile && cnt >= 16u * xcd_tile) {
+        w.xcd_tile = xcd_tile;
+        w.queue = queues + 16; // 8 counters, zeroed below
+        HIP_TRY(hipMemsetAsync(queues + 16, 0, 8 * 4, b->stream));
+      }
     }
     b->n_walk_dispatch++;
     HIP_TRY(hnyk_walk(b->g, w, b->shape, grid, b->stream));

@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   for (;;) {
     u32 m = 0;
     if (ln == 0) {
-      if (SP != 0 && !RM && a.xcd_tile) {
+      if (SP != 0 && a.xcd_tile) {
         // Tiles of xcd_tile consecutive members (locality order) go round-robin to the 8 XCDs, each
         // with its own counter: the waves of one XCD (= one L2) work on neighbouring queries while all
         // eight stay inside the same window of the batch (= one Infinity-Cache footprint).  A wave
