@@ -1131,6 +1131,30 @@ def test_tie_pool_overflow_fails_loudly(orc, hny):
     assert gg2.n_tie_pool_overflow == 0
 
 
+@pytest.mark.parametrize("tile", [16, 0])
+def test_xcd_tiled_search_queue_equals_oracle(orc, hny, monkeypatch, tile):
+    """Reader::nns for a batch of 9 000 queries on 1 KB rows: the locality-ordered layer-0 walks take
+    their queries from the 8 per-XCD counters (default tile 512 -> 8 192 queries and more; 16 forces many
+    small tiles and stealing): ids, distances and counts == the restated Reader"""
+    if tile:
+        monkeypatch.setenv("HNY_XCD_TILE", str(tile))
+    rng = np.random.default_rng(77)
+    n, dim, nq = 6000, 256, 9000
+    cent = rng.uniform(-1, 1, (16, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 16, n)] + 0.25 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, 1, vecs, draw_levels(n, 16, seed=6))
+    qs = (cent[rng.integers(0, 16, nq)] + 0.25 * rng.standard_normal((nq, dim))).astype(np.float32)
+    qc = orc.encode_vectors(1, qs)
+    qh = orc.make_headers(1, dim, qc)
+    with hny.Builder(items, M=16, M0=32, ef_construction=48, batch_frac=1.0, batch_max=4096) as b:
+        b.run()
+        g = b.finish()
+        ids, dists, counts = b.search_knn(qc, qh, k=10, ef_search=40)
+    oi, od, oc = orc.search(ds, g, qc, qh, k=10, ef_search=40, order=orc.ORDER_WAVE, threads=8)
+    assert np.array_equal(oc, counts) and np.array_equal(oi, ids)
+    assert np.array_equal(od.view(np.uint32), dists.view(np.uint32))
+
+
 def test_cross_lane_primitives_match_shfl_xor(hny):
     """xshfl<1..32> (DPP moves, v_permlane16/32_swap) and the swap-based fold steps == __shfl_xor on every
     lane, for u32 / f32 / u64 payloads: the distance reductions keep the wave order bit for bit"""
