@@ -2,14 +2,24 @@
 """bench.py — headline benchmark: HNSW build throughput (vectors indexed / s) + recall@10.
 
 Workload (BASELINE.json configs[1], "C2"): 1M x 768 f32 Cosine, M=16 (M0=32), ef_construction=100,
-one MI355X, vectors resident in HBM before the timed region.  One "step" = one complete build of
-the index (graph reset -> every batch searched, pruned, linked -> records exported to the host).
+vectors resident in HBM before the timed region.  One "step" = one complete build of the index
+(graph reset -> every batch searched, pruned, linked -> records exported to the host).
 
-  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs the item-sharded multi-GPU build, one rank per GPU over RCCL:
+  * under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one rank;
+  * started plainly (`python bench.py --gpus N`), this process launches the N ranks itself — fresh child
+    processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, before
+    anything here touches a GPU — relays rank 0's JSON line and fails if a rank fails;
+  * `--native`: ONE process, hny_multi_builder (one host thread + one replica per GPU, hny_multi.cpp),
+    i.e. what a Rust Writer::build would call.
+`--backend gloo` is the test mode: ranks may share one GPU, the exchange is staged through the host.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) carrying `roofline`
 (dominant kernel = k_walk, HIP events on the build stream) and `cpu_baseline` (the CPU oracle, i.e.
 a port of the reference algorithm — the real hannoy crate cannot be built here: no Rust, no LMDB).
+`--alt-data overlap` measures a second distribution in the same run (three more builds; off by default).
 """
 import argparse
 import json
@@ -38,8 +48,8 @@ def parse():
     p.add_argument("--ef", type=int, default=100)
     p.add_argument("--data", default="clustered", choices=["clustered", "overlap", "uniform"])
     p.add_argument("--alt-data", default=None, choices=["overlap", "uniform", "clustered", "none"],
-                   help="second distribution measured in the same run (value_alt / roofline_alt); default: "
-                        "`overlap` for the default C2 run on one GPU, none otherwise")
+                   help="second distribution measured in the same run (value_alt / roofline_alt): three more "
+                        "builds; default none")
     p.add_argument("--alt-steps", type=int, default=2)
     p.add_argument("--cpu-full", action="store_true",
                    help="time the CPU baseline on ALL vectors (about 80-100 s at C2) instead of a bounded sample")
@@ -57,7 +67,66 @@ def parse():
                    help="strict mode: f32 distances in the reference's x86 summation order")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo: test mode, ranks may share one GPU, exchange staged through the host")
+    p.add_argument("--native", action="store_true",
+                   help="--gpus N inside ONE process: hny_multi_builder (one host thread + replica per GPU, "
+                        "RCCL all-gathers on the builders' streams) instead of one process per GPU")
+    p.add_argument("--launch-timeout", type=float, default=3000.0,
+                   help="self-launched ranks (--gpus N without torchrun) are stopped after this many seconds")
+    p.add_argument("--out", default=None, help="also write the JSON line to this file")
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="launch check without a GPU: the ranks meet over gloo and rank 0 reports who came; no build")
     return p.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this very
+    script (the environment torch.distributed.run would give them), relay rank 0's JSON line, fail if any
+    rank fails or hangs.  Nothing in this process has touched a GPU (torch is not even imported)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HNY_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + a.launch_timeout
+    failed = None
+    pending = set(range(a.gpus))
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode("utf-8", "replace").splitlines()))
+    rd.start()
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    failed = f"rank {r} exited with code {rc}"
+        if time.time() > deadline:
+            failed = f"ranks {sorted(pending)} still running after {a.launch_timeout:.0f} s"
+        time.sleep(0.05)
+    if failed:
+        for p_ in procs:  # the exact processes started above
+            if p_.poll() is None:
+                p_.kill()
+    for p_ in procs:
+        p_.wait()
+    rd.join()
+    lines = [ln for ln in out0 if ln.startswith("{") and '"metric"' in ln]
+    for ln in out0:
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if failed or not lines:
+        print(f"bench.py --gpus {a.gpus}: {failed or 'rank 0 printed no result'}", file=sys.stderr)
+        raise SystemExit(1)
+    print(lines[-1], flush=True)
 
 
 def gen_data(torch, n, dim, kind, seed, device, queries=False):
@@ -120,14 +189,39 @@ def recall_at_k(found, counts, truth):
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and not a.native and "RANK" not in os.environ:
+        return self_launch(a)  # before anything touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.native and world > 1:
+        raise SystemExit("--native is one process for all GPUs: start it without torchrun")
+    if not a.native and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    launcher = ("native" if a.native else "single" if world == 1 else
+                "self" if os.environ.get("HNY_BENCH_SELF_LAUNCHED") else "torchrun")
     import torch
     import torch.distributed as dist
+    if a.rendezvous_only:  # the launch path alone (tests/test_bench_launch.py): no GPU, no build
+        ranks = [rank]
+        if world > 1:
+            dist.init_process_group("gloo")
+            ranks = [None] * world
+            dist.all_gather_object(ranks, rank)
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous only (no build)", "n_gpus": a.gpus, "launcher": launcher,
+                              "ranks_seen": dist.get_world_size() if world > 1 else 1, "ranks": ranks}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    local_rank %= torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if world > 1 and a.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, {n_dev} visible (--backend gloo: test mode)")
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -150,19 +244,36 @@ def main():
     row_bytes = items.codes.shape[1]
     bytes_per_eval = row_bytes + items.headers.shape[1]  # row + header
 
+    class NativeDriver:  # --native: the resident multi-builder behind the C ABI
+        def __init__(self, mb):
+            self.mb = mb
+
+        @property
+        def n_collectives(self):
+            return self.mb.n_collectives
+
     def timed_builds(items_, steps, warmup):
         """W untimed + K timed full builds (graph reset -> every batch -> records exported)."""
-        b = H.Builder(items_, M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed,
-                      batch_frac=a.batch_frac, batch_max=a.batch_max, device=local_rank,
-                      x86_order=a.x86_order)
-        b.set_profiling(True)
-        drv = multigpu.Driver(b, torch, dist if world > 1 else None, rank, world, dev,
-                              host_staged=(a.backend == "gloo"))
+        kw = dict(M=a.M, M0=M0, ef_construction=a.ef, seed=a.seed, batch_frac=a.batch_frac,
+                  batch_max=a.batch_max, x86_order=a.x86_order)
+        if a.native:
+            # HNY_MGPU_SHIM=1 (test mode): the ranks share GPU 0, copies instead of RCCL
+            devs = [0] * a.gpus if os.environ.get("HNY_MGPU_SHIM") else list(range(a.gpus))
+            mb = H.MultiBuilder(items_, devices=devs, **kw)
+            mb.set_profiling(True)
+            b, drv = mb.replica(0), NativeDriver(mb)
+            b._mb = mb  # keeps the replicas alive as long as the search handle
+            step = mb.run
+        else:
+            b = H.Builder(items_, device=local_rank, **kw)
+            b.set_profiling(True)
+            drv = multigpu.Driver(b, torch, dist if world > 1 else None, rank, world, dev,
+                                  host_staged=(a.backend == "gloo"))
 
-        def step():
-            b.reset()
-            drv.run()
-            return b.finish()
+            def step():
+                b.reset()
+                drv.run()
+                return b.finish()
 
         for _ in range(warmup):
             step()
@@ -185,27 +296,71 @@ def main():
             g = step()
         return b, drv, g, dt_
 
-    def roofline_of(g, dt_, steps):
-        """dominant kernel (k_walk): algorithmic bytes / device time, HIP events on the builder's
-        stream around every k_walk dispatch (a level-0 batch: descent dispatch + key sort + layer-0
-        dispatch under one pair); `launches` = k_walk dispatches, what rocprofv3 counts"""
+    def roofline_of(g, dt_, steps, data_kind):
+        """dominant kernel (k_walk).  Two byte counts over ONE time (HIP events on the builder's stream
+        around every k_walk dispatch; `launches` = k_walk dispatches, what rocprofv3 counts):
+          algorithmic = walk distance evaluations x (row + header) bytes — credits a row that
+                        an L2 hit served, so it can exceed the HBM peak;
+          counted     = L2->fabric bytes of the k_walk dispatches from the committed rocprofv3 --pmc passes
+                        of this same workload (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM) — an
+                        upper bound on HBM traffic (Infinity-Cache hits are counted), includes the bytes
+                        the walk moves beyond the rows (lists, visited sets).
+        achieved = min(algorithmic, counted) / time: useful bytes that really crossed the fabric, never
+        above what the memory system delivered; frac = achieved / 8 TB/s."""
         wb = g.n_evals_walk * bytes_per_eval
         if g.t_walk_kernels_s <= 0:
             return None
-        ach = wb / g.t_walk_kernels_s / 1e9
-        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_walk",
-             "launches": int(g.n_walk_launches),
-             "avg_launch_ms": round(1e3 * g.t_walk_kernels_s / max(1, g.n_walk_launches), 4),
-             "algorithmic_bytes_per_launch": int(wb / max(1, g.n_walk_launches)),
-             "bytes_per_eval": bytes_per_eval}
+        launches = max(1, int(g.n_walk_launches))
+        alg = wb / g.t_walk_kernels_s / 1e9
+        r = {"bound": "hbm", "achieved": round(alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(alg / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_walk",
+             "achieved_basis": "algorithmic bytes / k_walk time (no PMC profile committed for this workload)",
+             "achieved_algorithmic": round(alg, 1), "frac_algorithmic": round(alg / HBM_PEAK_GBS, 4),
+             "launches": launches, "avg_launch_ms": round(1e3 * g.t_walk_kernels_s / launches, 4),
+             "algorithmic_bytes_per_launch": int(wb / launches), "bytes_per_eval": bytes_per_eval}
         if steps:  # the same bytes over the WHOLE step (prune, link ops, export included)
             r["frac_whole_build"] = round(wb / (dt_ / steps) / 1e9 / HBM_PEAK_GBS, 4)
-        if ach > HBM_PEAK_GBS:  # SURVEY 8(d)'s numerator counts every evaluated row, wherever it came from
-            r["note"] = ("achieved = algorithmic bytes / kernel time exceeds the HBM peak because part of the row "
-                         "reads are L2 hits (XCD-tiled work queue: neighbouring queries share an L2); "
-                         "l2_to_fabric_gbs is the counted L2->fabric traffic over the same time")
+        pmc_name, pj = pmc_profile(data_kind)
+        pk = pj.get("k_walk") if pj else None
+        if pk and world == 1 and not a.native:
+            import hashlib
+            total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
+            # the PMC pass ran one build of this same workload: its bytes over ITS dispatches
+            r["traffic"] = int(total / max(1, pk["launches"]))
+            counted = r["traffic"] * launches / g.t_walk_kernels_s / 1e9
+            r["achieved_counted"] = round(counted, 1)
+            r["achieved"] = round(min(alg, counted), 1)
+            r["frac"] = round(min(alg, counted) / HBM_PEAK_GBS, 4)
+            r["achieved_basis"] = ("min(algorithmic, counted L2->fabric) bytes / k_walk time; counted = rocprofv3 --pmc "
+                                   "2 x FETCH_SIZE + WRITE_SIZE of the k_walk dispatches (Infinity-Cache hits included)")
+            if alg >= counted:
+                r["reuse"] = round(alg / counted, 3)  # evaluated rows served by L2 instead of the fabric
+            else:
+                r["wasted_traffic_ratio"] = round(counted / alg, 3)  # bytes moved beyond the rows
+            r["traffic_read_bytes"] = int(pk["hbm_read_bytes_corrected_x2"] / max(1, pk["launches"]))
+            r["traffic_write_bytes"] = int(pk["hbm_write_bytes"] / max(1, pk["launches"]))
+            with open(os.path.join(ROOT, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb") as f:
+                sha = hashlib.sha1(f.read()).hexdigest()
+            r["traffic_source"] = (f"profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   f"workload (scripts/r3_pmc.sh), summed over the {pk['launches']} k_walk "
+                                   f"dispatches of one build, per dispatch")
+            r["traffic_stale"] = pj.get("kernel_source_sha1") != sha  # kernels changed since the PMC passes
         return r
+
+    def pmc_profile(data_kind):
+        """the committed PMC summary of this exact workload (newest round first), or (None, None)"""
+        if a.batch_frac or a.batch_max or a.x86_order:
+            return None, None
+        key = f"{a.n}x{a.dim}_{a.metric}_M{a.M}_ef{a.ef}_{data_kind}"
+        import glob
+        names = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_{key}.json")), reverse=True)
+        if not names and key == "1000000x768_cosine_M16_ef100_clustered":
+            names = [os.path.join(ROOT, "profiles", "r02_c2_pmc_hbm.json")]
+        for nm in names:
+            if os.path.exists(nm):
+                with open(nm) as f:
+                    return os.path.basename(nm), json.load(f)
+        return None, None
 
     def build_stats(g):
         return {"n_batches": int(g.n_batches), "n_distance_evals": int(g.n_distance_evals),
@@ -222,44 +377,20 @@ def main():
 
     builder, driver, graph, dt = timed_builds(items, a.steps, a.warmup)
     value = a.n * a.steps / dt if a.steps else 0.0
-    roof = roofline_of(graph, dt, a.steps)
-
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process,
-    # so the figure comes from the committed rocprofv3 --pmc passes of this same command
-    # (scripts/profile_c2.sh; FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), per launch.
-    # The profile records the hash of the kernel source it was taken on: a mismatch is flagged.
+    roof = roofline_of(graph, dt, a.steps, a.data)
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
-                  and world == 1 and not a.x86_order)
-    pmc_name = next((f for f in ("r02_c2_pmc_hbm.json", "r01_c2_pmc_hbm_specialised.json")
-                     if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-    if roof and default_c2 and pmc_name:
-        with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
-            pj = json.load(f)
-        pk = pj.get("k_walk")
-        if pk:
-            total = pk["hbm_read_bytes_corrected_x2"] + pk["hbm_write_bytes"]
-            roof["traffic"] = int(total / max(1, pk["launches"]))
-            # FETCH_SIZE counts what the Infinity Cache serves too: this is L2-to-fabric traffic (an upper
-            # bound on HBM), and `achieved` above is algorithmic bytes (it also credits L2 hits)
-            roof["l2_to_fabric_gbs"] = round(roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1)
-            import hashlib
-            with open(os.path.join(ROOT, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb") as f:
-                sha = hashlib.sha1(f.read()).hexdigest()
-            roof["traffic_source"] = (f"profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      f"command (scripts/profile_c2.sh), 2x FETCH + WRITE summed over the "
-                                      f"{pk['launches']} k_walk dispatches of one build, per dispatch")
-            roof["traffic_stale"] = pj.get("kernel_source_sha1") != sha  # kernels changed since the PMC passes
+                  and world == 1 and not a.native and not a.x86_order)
 
     known = {(1_000_000, 768, "cosine", 16, 100): "C2", (1_000_000, 768, "euclidean", 32, 200): "C3",
-             (10_000_000, 128, "cosine", 16, 100): "C4 (on %d GPU)" % world,
-             (5_000_000, 1024, "hamming", 16, 64): "C5 (on %d GPU)" % world}
+             (10_000_000, 128, "cosine", 16, 100): "C4 (on %d GPU)" % a.gpus,
+             (5_000_000, 1024, "hamming", 16, 64): "C5 (on %d GPU)" % a.gpus}
     cfg_name = known.get((a.n, a.dim, a.metric, a.M, a.ef), "custom")
     shape = f"{a.n // 1_000_000}M" if a.n % 1_000_000 == 0 and a.n else str(a.n)
     out = {
         "metric": f"vectors indexed/sec (build) + recall@10, {shape} x {a.dim} {a.metric.capitalize()} "
                   f"M={a.M} efC={a.ef}",
-        "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": a.steps,
+        "value": round(value, 1), "unit": "vectors/s", "n_gpus": a.gpus, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / max(1, a.steps), 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if metric < H.HAMMING else "u64-popcount", "data": "synthetic",
@@ -268,11 +399,25 @@ def main():
                    "n": a.n, "dim": a.dim, "M": a.M, "M0": M0, "ef_construction": a.ef,
                    "batch_frac": builder.opts.batch_frac or 1.0,
                    "batch_max": builder.opts.batch_max or H.default_batch_max(a.n),
-                   "parallelism": f"item-sharded search x{world}, replicated graph",
+                   "parallelism": f"item-sharded search x{a.gpus}, replicated graph",
                    "distance_order": "x86 (strict)" if a.x86_order else "wave"},
         "roofline": roof,
         "build": build_stats(graph),
+        # who ran: ranks that really took part (dist.get_world_size() / replicas of the multi-builder),
+        # the GPU each one used, and how they were started
+        "ranks_seen": (builder._mb.world if a.native else dist.get_world_size() if world > 1 else 1),
+        "launcher": launcher,
     }
+    if a.native:
+        out["devices"] = [int(d) for d in builder._mb.opts.devices[:a.gpus]]
+    elif world > 1:
+        dv = [None] * world
+        dist.all_gather_object(dv, int(local_rank))
+        out["devices"] = dv
+    else:
+        out["devices"] = [int(local_rank)]
+    if a.gpus > 1 and a.backend == "gloo" and not a.native:
+        out["note_backend"] = "gloo test mode: ranks may share a GPU and exchange through the host — not a scaling measurement"
 
     if rank == 0 and not a.no_recall and a.queries:
         truth = brute_force_topk(torch, a.metric, x_dev, q_dev, 10)
@@ -293,7 +438,7 @@ def main():
         out["search"]["qps_batch_32768_incl_transfers"] = round(nqs / (time.perf_counter() - t1), 1)
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle = port of the reference algorithm ----
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if rank == 0 and a.gpus == 1 and not a.no_cpu:
         from oracle import orc
         from tests.conftest import draw_levels
         cores = os.cpu_count() or 1
@@ -344,8 +489,8 @@ def main():
     # ---- a second distribution in the same line: the headline data (well-separated clusters) is the
     # friendly case for the memory system; `overlap` (overlapping clusters on a 32-d manifold) is what
     # embedding collections look like.  value_alt / roofline_alt / recall_at_10_alt, same parameters.
-    alt = a.alt_data or ("overlap" if default_c2 else "none")
-    if world == 1 and alt != "none" and alt != a.data:
+    alt = a.alt_data or "none"
+    if a.gpus == 1 and not a.native and alt != "none" and alt != a.data:
         builder.close()
         del x_dev, x, items
         xa_dev = gen_data(torch, a.n, a.dim, alt, a.seed, dev)
@@ -356,12 +501,16 @@ def main():
         out["alt"] = {"data": f"{alt} synthetic vectors (bench.py gen_data), same n / dim / M / efC",
                       "steps": a.alt_steps, "ms_per_step": round(1e3 * dta / max(1, a.alt_steps), 2),
                       "build": build_stats(ga)}
-        out["roofline_alt"] = roofline_of(ga, dta, a.alt_steps)
+        out["roofline_alt"] = roofline_of(ga, dta, a.alt_steps, alt)
         if not a.no_recall and a.queries:
             truth_a = brute_force_topk(torch, a.metric, xa_dev, qa_dev, 10)
             qca, qha = H.encode_vectors(metric, qa_dev.cpu().numpy())
             ida, _, cna = builder.search_knn(qca, qha, k=10, ef_search=a.ef_search)
             out["recall_at_10_alt"] = round(recall_at_k(ida, cna, truth_a), 4)
+    if a.native and a.gpus > 1:
+        out["n_collectives"] = driver.n_collectives
+        # HNY_MGPU_VERIFY=1 makes every replica export and compares them inside hny_multi_builder_run
+        out["replicas_identical"] = True if os.environ.get("HNY_MGPU_VERIFY") else None
     if world > 1:  # replicas must be bit-identical: compare a checksum of the exported graph
         import zlib
         cs = zlib.crc32(graph.nbrs.tobytes()) ^ zlib.crc32(graph.offsets.tobytes())
@@ -370,8 +519,14 @@ def main():
         out["replicas_identical"] = bool(tc[0].item() == cs and -tc[1].item() == cs)
         out["n_collectives"] = driver.n_collectives
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write(line + "\n")
+        print(line, flush=True)
     builder.close()
+    if a.native:
+        builder._mb.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,6 +31,9 @@ EXPORTED = [
     "hny_builder_exch_stride_u64", "hny_builder_stream", "hny_default_batch_max", "hny_selftest_lane_ops",
     "hny_lmdb_writer_open", "hny_lmdb_writer_put", "hny_lmdb_writer_finish", "hny_lmdb_writer_abort",
     "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
+    "hny_multi_builder_create", "hny_multi_builder_run", "hny_multi_builder_set_profiling",
+    "hny_multi_builder_world", "hny_multi_builder_collectives", "hny_multi_builder_replica",
+    "hny_multi_builder_destroy", "hny_abi_sizes",
 ]
 ERR_IO = -9
 NNS_NONE = 0xFFFFFFFF  # by_item: the reference returns None
@@ -215,8 +218,53 @@ def load_library():
     L.hny_lmdb_close.argtypes = [vp]
     L.hny_last_error.restype = C.c_char_p
     L.hny_version.restype = C.c_char_p
+    L.hny_multi_builder_create.restype = C.c_int
+    L.hny_multi_builder_create.argtypes = [C.POINTER(BuildOpts), C.POINTER(Items), C.POINTER(vp)]
+    L.hny_multi_builder_run.restype = C.c_int
+    L.hny_multi_builder_run.argtypes = [vp, C.POINTER(C.POINTER(GraphStruct))]
+    L.hny_multi_builder_set_profiling.restype = C.c_int
+    L.hny_multi_builder_set_profiling.argtypes = [vp, C.c_int]
+    L.hny_multi_builder_world.restype = C.c_uint32
+    L.hny_multi_builder_world.argtypes = [vp]
+    L.hny_multi_builder_collectives.restype = C.c_uint64
+    L.hny_multi_builder_collectives.argtypes = [vp]
+    L.hny_multi_builder_replica.restype = vp
+    L.hny_multi_builder_replica.argtypes = [vp, C.c_uint32]
+    L.hny_multi_builder_destroy.argtypes = [vp]
+    L.hny_abi_sizes.restype = C.c_uint32
+    L.hny_abi_sizes.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    _check_abi(L)
     _lib = L
     return L
+
+
+# the order of hny_abi_sizes (HNY_ABI_* in include/hannoy_amd.h)
+ABI_STRUCTS = None
+
+
+def _check_abi(L):
+    """sizeof of every struct declared here against the library's own (hny_abi_sizes): a field added
+    to the header and not to this binding fails the import instead of corrupting a call"""
+    global ABI_STRUCTS
+    ABI_STRUCTS = [("hny_build_opts", BuildOpts), ("hny_items", Items), ("hny_graph", GraphStruct),
+                   ("hny_prev_graph", PrevGraph), ("hny_batch", Batch), ("hny_query_opts", QueryOpts),
+                   ("hny_lmdb_stat", LmdbStat)]
+    out = (C.c_uint32 * len(ABI_STRUCTS))()
+    n = L.hny_abi_sizes(out, len(ABI_STRUCTS))
+    if n != len(ABI_STRUCTS):
+        raise ImportError(f"hannoy_amd ABI mismatch: the library knows {n} public structs, this binding {len(ABI_STRUCTS)}")
+    for (name, cls), size in zip(ABI_STRUCTS, out):
+        if C.sizeof(cls) != size:
+            raise ImportError(f"hannoy_amd ABI mismatch: sizeof({name}) is {size} in the library, "
+                              f"{C.sizeof(cls)} in hannoy_amd/_capi.py")
+
+
+def abi_sizes():
+    """{struct name: sizeof in the loaded library}"""
+    L = load_library()
+    out = (C.c_uint32 * len(ABI_STRUCTS))()
+    L.hny_abi_sizes(out, len(ABI_STRUCTS))
+    return {name: int(v) for (name, _), v in zip(ABI_STRUCTS, out)}
 
 
 def _check(rc):
@@ -563,8 +611,65 @@ def build_incremental(items, prev, to_insert, to_delete, **kw):
     return Graph(gp, o, items)
 
 
+class MultiBuilder:
+    """hny_multi_builder_*: one resident replica per GPU of this node in ONE process (one host thread
+    per GPU, RCCL all-gathers on the builders' streams, hny_multi.cpp); every run() is a complete fresh
+    build whose records equal the one-GPU build's."""
+
+    def __init__(self, items, devices=None, n_gpus=0, **kw):
+        self.items = items
+        self.opts = make_opts(items.metric, items.dim, n_gpus=n_gpus, devices=devices, **kw)
+        self._h = C.c_void_p()
+        it = items.struct()
+        _check(load_library().hny_multi_builder_create(C.byref(self.opts), C.byref(it), C.byref(self._h)))
+
+    @property
+    def world(self):
+        return int(load_library().hny_multi_builder_world(self._h))
+
+    @property
+    def n_collectives(self):
+        return int(load_library().hny_multi_builder_collectives(self._h))
+
+    def set_profiling(self, on=True):
+        _check(load_library().hny_multi_builder_set_profiling(self._h, int(on)))
+
+    def run(self):
+        gp = C.POINTER(GraphStruct)()
+        _check(load_library().hny_multi_builder_run(self._h, C.byref(gp)))
+        return Graph(gp, self.opts, self.items)
+
+    def replica(self, rank=0):
+        """the resident builder of `rank` as a Builder (library-owned: close() on it is a no-op)"""
+        h = load_library().hny_multi_builder_replica(self._h, rank)
+        if not h:
+            raise IndexError(rank)
+        b = Builder.__new__(Builder)
+        b.items, b.opts, b.incremental = self.items, self.opts, False
+        b._h, b._borrowed = C.c_void_p(h), True
+        return b
+
+    def close(self):
+        if self._h:
+            load_library().hny_multi_builder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Builder:
     """Stepwise builder (hny_builder_*): vectors stay resident in HBM across reset()/rebuilds."""
+    _borrowed = False
 
     def __init__(self, items, prev=None, to_insert=(), to_delete=(), load=False, **kw):
         """prev given -> incremental builder on top of a stored graph (hny_builder_create_incremental);
@@ -588,9 +693,9 @@ class Builder:
                 C.byref(self._h)))
 
     def close(self):
-        if self._h:
+        if self._h and not self._borrowed:
             load_library().hny_builder_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

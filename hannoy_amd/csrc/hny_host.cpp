@@ -469,6 +469,14 @@ extern "C" {
 
 const char *hny_last_error(void) { return g_err.c_str(); }
 const char *hny_version(void) { return "hannoy_amd 0.1.0 (gfx950)"; }
+uint32_t hny_abi_sizes(uint32_t *out, uint32_t n) {
+  const uint32_t sizes[HNY_ABI_N_STRUCTS] = {
+      (uint32_t)sizeof(hny_build_opts), (uint32_t)sizeof(hny_items),      (uint32_t)sizeof(hny_graph),
+      (uint32_t)sizeof(hny_prev_graph), (uint32_t)sizeof(hny_batch),      (uint32_t)sizeof(hny_query_opts),
+      (uint32_t)sizeof(hny_lmdb_stat)};
+  for (uint32_t i = 0; out && i < n && i < HNY_ABI_N_STRUCTS; i++) out[i] = sizes[i];
+  return HNY_ABI_N_STRUCTS;
+}
 
 size_t hny_vector_bytes(int32_t metric, uint32_t dim) { return vec_bytes(metric, dim); }
 size_t hny_header_bytes(int32_t metric) { return hdr_bytes(metric); }
@@ -1359,7 +1367,9 @@ static int apply_front(hny_builder *b, const void *sel_dev, ApplyArgs &a) {
   a.n_deferred = b->d_nseg.p + 1;
   const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
   prof_begin(b, EV_APPLY);
-  if (a.deferred && env_int("HNY_APPLY_WAVE", 0) == 0)
+  // HNY_APPLY_WAVE=1 (one wave per target, k_apply) keeps one lane per list slot: lists of more than
+  // HNY_MAX_CAP slots always take the append + workgroup path
+  if (a.deferred && (env_int("HNY_APPLY_WAVE", 0) == 0 || std::max(b->g.M0, b->g.M) > (u32)HNY_MAX_CAP))
     HIP_TRY(hnyk_apply_append(b->g, a, b->stream)); // appends: one thread per target
   else
     HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream)); // one wave per target, prunes included
@@ -1491,6 +1501,20 @@ static int pool_overflow_error(hny_builder *b, unsigned long long n) {
               "at once) — the graph would differ from the reference's", n, HNY_POOL_CAP);
 }
 
+// what the kernels report through the error words of a counter block: reported once (HNY_ERR_DEVICE), then
+// cleared, so that a later reset / search starts clean
+static int device_error_words(hny_builder *b, const u64 *stats) {
+  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER] || stats[ST_ERR_GAPS_OVERFLOW]) {
+    (void)clear_error_counters(b);
+    return fail(HNY_ERR_DEVICE,
+                "kernel overflow: res=%llu iter=%llu gaps=%llu (res: a walk's result set outgrew its %u entries — a walk "
+                "that starts from more entry points than its ef keeps every closer point, see res_capacity / DESIGN.md limits)",
+                stats[ST_ERR_RES_OVERFLOW], stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW], b->rcap);
+  }
+  if (stats[ST_POOL_OVERFLOW]) return pool_overflow_error(b, stats[ST_POOL_OVERFLOW]);
+  return HNY_OK;
+}
+
 void hny_graph_free(hny_graph *g) {
   if (!g) return;
   free((void *)g->rec_item);
@@ -1513,14 +1537,7 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   const uint32_t n = b->n, M = b->o.M, M0 = b->o.M0, ml = b->max_level;
   u64 stats[ST_COUNT] = {0};
   HIP_TRY(hipMemcpy(stats, b->d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  if (stats[ST_ERR_RES_OVERFLOW] || stats[ST_ERR_ITER] || stats[ST_ERR_GAPS_OVERFLOW]) {
-    (void)clear_error_counters(b); // reported once: a later reset / search starts clean
-    return fail(HNY_ERR_DEVICE,
-                "kernel overflow: res=%llu iter=%llu gaps=%llu (res: a walk's result set outgrew its %u entries — a walk "
-                "that starts from more entry points than its ef keeps every closer point, see res_capacity / DESIGN.md limits)",
-                stats[ST_ERR_RES_OVERFLOW], stats[ST_ERR_ITER], stats[ST_ERR_GAPS_OVERFLOW], b->rcap);
-  }
-  if (stats[ST_POOL_OVERFLOW]) return pool_overflow_error(b, stats[ST_POOL_OVERFLOW]);
+  if (int rc = device_error_words(b, stats)) return rc;
   // finalise every list on the device (sort + dedup), then copy through pinned staging
   const uint32_t upl = b->up_layers;
   const size_t nup = (size_t)b->n_upper * upl;
@@ -1809,7 +1826,9 @@ extern "C" int hny_internal_builder_read_evals(hny_builder *b, uint64_t out3[3])
   out3[0] = stats[ST_EVALS_WALK];
   out3[1] = stats[ST_EVALS_PRUNE];
   out3[2] = stats[ST_EVALS_APPLY];
-  return HNY_OK;
+  // the error words of THIS replica: an overflow inside the shard a rank >= 1 searched shows up nowhere
+  // else (hny_multi.cpp folds the result into the ranks' agreement, so the whole build fails with it)
+  return device_error_words(b, stats);
 }
 
 int hny_builder_fill_gaps(hny_builder *b) {

@@ -53,6 +53,7 @@ struct Rccl {
   void *handle = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr; // optional
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -73,6 +74,7 @@ int load_rccl() {
   r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
   r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+  r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
     return failf(HNY_ERR_NO_DEVICE, "multi-GPU build: librccl lacks an expected symbol");
@@ -128,6 +130,7 @@ struct Shared {
 struct Exchange {
   virtual ~Exchange() {}
   virtual int all_gather(int rank, void *buf, size_t bytes, hipStream_t st) = 0;
+  virtual void abort(int rank) { (void)rank; } // a peer failed between enqueue and completion
 };
 
 struct RcclExchange : Exchange {
@@ -146,8 +149,15 @@ struct RcclExchange : Exchange {
     }
     return HNY_OK;
   }
+  void abort(int rank) override {
+    if (g_rccl.CommAbort && comms[rank]) {
+      (void)g_rccl.CommAbort(comms[rank]); // frees the communicator too
+      comms[rank] = nullptr;
+    }
+  }
   int all_gather(int rank, void *buf, size_t bytes, hipStream_t st) override {
     if (!bytes) return HNY_OK;
+    if (!comms[rank]) return failf(HNY_ERR_DEVICE, "ncclAllGather: communicator aborted");
     ncclResult_t r = g_rccl.AllGather((const char *)buf + (size_t)rank * bytes, buf, bytes, ncclUint8, comms[rank], st);
     if (r != ncclSuccess) return failf(HNY_ERR_DEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(r));
     return HNY_OK;
@@ -188,9 +198,12 @@ struct DevMem {
     bytes = need;
     return HNY_OK;
   }
-  ~DevMem() {
+  void release() {
     if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
   }
+  ~DevMem() { release(); }
 };
 
 int env_int(const char *name, int dflt) {
@@ -209,11 +222,39 @@ struct Job {
 extern "C" int hny_internal_builder_count_evals(hny_builder *b, int on);
 extern "C" int hny_internal_builder_read_evals(hny_builder *b, uint64_t out3[3]);
 
-// the batch loop of one rank (hny_build's loop with the two exchanges in it)
-int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny_graph **out, uint64_t *checksum) {
-  const int world = sh.world;
-  hny_build_opts o = *job.opts;
-  o.device = device;
+} // namespace
+
+// A resident multi-GPU build: one hny_builder (full replica of the vectors in HBM) per GPU, one
+// communicator, the exchange buffers — created once, run any number of times (hny_multi_builder_run =
+// graph reset + every batch + export, like hny_builder_reset / next_batch.. / finish on one GPU).
+struct hny_multi_builder {
+  int world = 1;
+  std::vector<int> devices;
+  hny_build_opts opts{};           // the caller's options (callbacks included), devices -> this->devices
+  Shared sh;
+  std::unique_ptr<Exchange> ex;
+  std::vector<hny_builder *> b;    // one per rank
+  std::vector<DevMem> sel, exch;   // per rank, allocated on the rank's device
+  bool incremental = false, ran = false, profiling = false;
+  uint64_t n_items = 0;
+  uint64_t n_collectives = 0;      // of the last run (rank 0's count; every rank issues the same)
+  explicit hny_multi_builder(int w) : world(w), sh(w), b(w, nullptr), sel(w), exch(w) {}
+  ~hny_multi_builder() {
+    for (int r = 0; r < world; r++) {
+      (void)hipSetDevice(devices.empty() ? 0 : devices[r]);
+      sel[r].release();
+      exch[r].release();
+      if (b[r]) hny_builder_destroy(b[r]);
+    }
+  }
+};
+
+namespace {
+
+// rank r's part of hny_multi_builder_create: its replica
+int create_rank(hny_multi_builder &mb, int rank, const Job &job) {
+  hny_build_opts o = mb.opts;
+  o.device = mb.devices[rank];
   o.n_gpus = 0;
   o.devices = nullptr;
   if (rank != 0) { // callbacks fire on rank 0 only
@@ -224,22 +265,45 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
   int rc = job.prev ? hny_builder_create_incremental(&o, job.items, job.to_insert, job.n_insert, job.to_delete,
                                                      job.n_delete, job.prev, &b)
                     : hny_builder_create(&o, job.items, &b);
-  std::unique_ptr<hny_builder, void (*)(hny_builder *)> guard(b, hny_builder_destroy);
+  mb.b[rank] = b;
+  return mb.sh.agree(rank, rc);
+}
+
+// the batch loop of one rank (hny_build's loop with the two exchanges in it)
+int run_rank(hny_multi_builder &mb, int rank, hny_graph **out, uint64_t *checksum) {
+  Shared &sh = mb.sh;
+  Exchange &ex = *mb.ex;
+  const int world = sh.world;
+  const int device = mb.devices[rank];
+  hny_builder *b = mb.b[rank];
+  const hny_build_opts &opts = mb.opts;
+  int rc = hipSetDevice(device) == hipSuccess ? HNY_OK : failf(HNY_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+  if (!rc && mb.ran) rc = hny_builder_reset(b); // a second run: empty graph again, vectors stay in HBM
+  if (!rc) rc = hny_internal_builder_count_evals(b, 1);
+  if (!rc) rc = hny_builder_set_profiling(b, mb.profiling ? 1 : 0);
   rc = sh.agree(rank, rc);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)hny_builder_stream(b);
-  (void)hipSetDevice(device);
-  DevMem sel, exch;
+  DevMem &sel = mb.sel[rank], &exch = mb.exch[rank];
   const uint32_t min_shard = (uint32_t)std::max(1, env_int("HNY_MGPU_MIN_BATCH", 64 * world));
   const uint32_t min_def = (uint32_t)std::max(1, env_int("HNY_MGPU_MIN_DEFERRED", 32 * world));
   const uint32_t xs = hny_builder_exch_stride_u64(b);
-  uint64_t done = 0, total = 0;
+  uint64_t done = 0, total = 0, n_coll = 0;
   // evaluation counters: what every rank repeats counts once (on rank 0), the shards add up
   auto replicated = [&](bool yes) -> int { return rank ? hny_internal_builder_count_evals(b, yes ? 0 : 1) : 0; };
+  // a collective is enqueued by every rank or by none: the ranks agree before it, and once more after the
+  // enqueue — a rank whose ncclAllGather failed must not leave its peers waiting inside theirs
+  auto gather = [&](void *buf, size_t bytes) -> int {
+    int r = ex.all_gather(rank, buf, bytes, st);
+    n_coll++;
+    r = sh.agree(rank, r);
+    if (r) ex.abort(rank); // releases a collective this rank has already enqueued
+    return r;
+  };
   for (;;) {
     int cancelled = 0;
-    if (job.opts->cancel) { // polled by rank 0 before every batch, obeyed by all (lib.rs:140)
-      if (rank == 0) cancelled = job.opts->cancel(job.opts->cancel_ctx) ? HNY_ERR_CANCELLED : 0;
+    if (opts.cancel) { // polled by rank 0 before every batch, obeyed by all (lib.rs:140)
+      if (rank == 0) cancelled = opts.cancel(opts.cancel_ctx) ? HNY_ERR_CANCELLED : 0;
       if (rank == 0 && cancelled) (void)failf(HNY_ERR_CANCELLED, "build cancelled");
       cancelled = sh.agree(rank, cancelled);
       if (cancelled) return cancelled;
@@ -263,9 +327,10 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
       if (!rc) rc = hny_builder_search(b, lo, hi, sel.p);
       rc = sh.agree(rank, rc);
       if (rc) return rc;
-      rc = ex.all_gather(rank, sel.p, (size_t)per * bt.sel_stride_u64 * 8, st);
+      rc = gather(sel.p, (size_t)per * bt.sel_stride_u64 * 8);
+      if (rc) return rc;
       uint32_t nd = 0;
-      if (!rc) rc = hny_builder_apply_begin(b, sel.p, &nd); // the same number on every rank
+      rc = hny_builder_apply_begin(b, sel.p, &nd); // the same number on every rank
       if (!rc && nd < min_def) {
         rc = replicated(true);
         if (!rc) rc = hny_builder_apply_deferred(b, 0, 1, nullptr);
@@ -277,26 +342,32 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
         if (!rc) rc = hny_builder_apply_deferred(b, (uint32_t)rank, (uint32_t)world, exch.p);
         rc = sh.agree(rank, rc);
         if (rc) return rc;
-        rc = ex.all_gather(rank, exch.p, (size_t)per2 * xs * 8, st);
-        if (!rc) rc = hny_builder_apply_merge(b, exch.p, (uint32_t)rank, (uint32_t)world);
+        rc = gather(exch.p, (size_t)per2 * xs * 8);
+        if (rc) return rc;
+        rc = hny_builder_apply_merge(b, exch.p, (uint32_t)rank, (uint32_t)world);
         if (rc) return sh.agree(rank, rc);
       }
     }
     done += bt.count;
-    if (rank == 0 && job.opts->progress) {
-      if (!total) total = job.prev ? done : job.items->n;
-      job.opts->progress(job.opts->progress_ctx, done, std::max(total, done));
+    if (rank == 0 && opts.progress) {
+      if (!total) total = mb.incremental ? done : mb.n_items;
+      opts.progress(opts.progress_ctx, done, std::max(total, done));
     }
   }
-  if (job.prev) { // fill_gaps_from_deleted (hnsw.rs:187): deterministic, every replica does it
+  if (mb.incremental) { // fill_gaps_from_deleted (hnsw.rs:187): deterministic, every replica does it
     rc = replicated(true);
     if (!rc) rc = hny_builder_fill_gaps(b);
     if (rc) return sh.agree(rank, rc);
   }
+  // Every rank reads its own counters AND its own device error words here: an overflow of the tie pool or
+  // of a result set inside the shard of a rank >= 1 exists only in that rank's counter block (rank 0 never
+  // walked those members), and the clipped selection has already been all-gathered into every replica —
+  // so it must fail the whole build, as it does on one GPU (hny_builder_finish).
   rc = replicated(false);
   if (!rc) rc = hny_internal_builder_read_evals(b, &sh.evals[(size_t)rank * 3]);
   rc = sh.agree(rank, rc);
   if (rc) return rc;
+  if (rank == 0) mb.n_collectives = n_coll;
   const bool verify = env_int("HNY_MGPU_VERIFY", 0) != 0;
   if (rank == 0 || verify) {
     hny_graph *g = nullptr;
@@ -325,61 +396,83 @@ int run_rank(int rank, int device, const Job &job, Shared &sh, Exchange &ex, hny
   return rc;
 }
 
-} // namespace
+// runs fn(rank) on one host thread per rank (rank 0 = the caller's thread: callbacks fire there) and
+// reports the first failure with the message of the rank that failed first
+template <class F>
+int on_all_ranks(hny_multi_builder &mb, F &&fn) {
+  const int world = mb.world;
+  std::vector<int> rcs(world, 0);
+  std::vector<std::string> msgs(world);
+  for (auto &m : mb.sh.msg) m.clear();
+  std::fill(mb.sh.rc.begin(), mb.sh.rc.end(), 0);
+  std::vector<std::thread> th;
+  for (int r = 1; r < world; r++)
+    th.emplace_back([&, r]() {
+      rcs[r] = fn(r);
+      if (rcs[r]) msgs[r] = hny_last_error();
+    });
+  rcs[0] = fn(0);
+  if (rcs[0]) msgs[0] = hny_last_error();
+  for (auto &t : th) t.join();
+  for (int r = 0; r < world; r++)
+    if (rcs[r]) {
+      // the rank that failed first holds the message (the others report "a peer failed")
+      for (int q = 0; q < world; q++)
+        if (!mb.sh.msg[q].empty()) return hny_internal_fail(mb.sh.rc[q] ? mb.sh.rc[q] : rcs[r], mb.sh.msg[q].c_str());
+      return hny_internal_fail(rcs[r], msgs[r].empty() ? "multi-GPU build failed" : msgs[r].c_str());
+    }
+  return HNY_OK;
+}
 
-extern "C" int hny_internal_build_multi(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
-                                        uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
-                                        const hny_prev_graph *prev, hny_graph **out) {
+int create_multi(const Job &job, hny_multi_builder **out) {
   *out = nullptr;
+  const hny_build_opts *opts = job.opts;
   const int world = opts->n_gpus;
   if (world < 1 || world > 64) return failf(HNY_ERR_INVALID_ARG, "n_gpus %d outside [1, 64]", world);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return failf(HNY_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
-  std::vector<int> devices(world);
+  std::unique_ptr<hny_multi_builder> mb(new hny_multi_builder(world));
+  mb->devices.resize(world);
   for (int r = 0; r < world; r++) {
-    devices[r] = opts->devices ? opts->devices[r] : r;
-    if (devices[r] < 0 || devices[r] >= ndev)
-      return failf(HNY_ERR_NO_DEVICE, "device %d of rank %d: %d devices visible", devices[r], r, ndev);
+    mb->devices[r] = opts->devices ? opts->devices[r] : r;
+    if (mb->devices[r] < 0 || mb->devices[r] >= ndev)
+      return failf(HNY_ERR_NO_DEVICE, "device %d of rank %d: %d devices visible", mb->devices[r], r, ndev);
   }
   const bool shim = env_int("HNY_MGPU_SHIM", 0) != 0;
   if (!shim)
     for (int r = 0; r < world; r++)
       for (int q = 0; q < r; q++)
-        if (devices[q] == devices[r]) return failf(HNY_ERR_INVALID_ARG, "device %d listed twice", devices[r]);
-  Shared sh(world);
-  std::unique_ptr<Exchange> ex;
+        if (mb->devices[q] == mb->devices[r]) return failf(HNY_ERR_INVALID_ARG, "device %d listed twice", mb->devices[r]);
   if (shim) {
-    ex.reset(new ShimExchange(&sh));
+    mb->ex.reset(new ShimExchange(&mb->sh));
   } else {
     std::unique_ptr<RcclExchange> rx(new RcclExchange());
-    if (int rc = rx->init(devices)) return rc;
-    ex = std::move(rx);
+    if (int rc = rx->init(mb->devices)) return rc;
+    mb->ex = std::move(rx);
   }
-  Job job{opts, items, to_insert, to_delete, n_insert, n_delete, prev};
-  std::vector<int> rcs(world, 0);
-  std::vector<std::string> msgs(world);
-  std::vector<uint64_t> sums(world, 0);
-  std::vector<std::thread> th;
-  for (int r = 1; r < world; r++)
-    th.emplace_back([&, r]() {
-      rcs[r] = run_rank(r, devices[r], job, sh, *ex, out, &sums[r]);
-      if (rcs[r]) msgs[r] = hny_last_error();
-    });
-  rcs[0] = run_rank(0, devices[0], job, sh, *ex, out, &sums[0]); // callbacks run on the caller's thread
-  if (rcs[0]) msgs[0] = hny_last_error();
-  for (auto &t : th) t.join();
-  for (int r = 0; r < world; r++)
-    if (rcs[r]) {
-      if (*out) hny_graph_free(*out);
-      *out = nullptr;
-      // the rank that failed first holds the message (the others report "a peer failed")
-      for (int q = 0; q < world; q++)
-        if (!sh.msg[q].empty()) return hny_internal_fail(sh.rc[q] ? sh.rc[q] : rcs[r], sh.msg[q].c_str());
-      return hny_internal_fail(rcs[r], msgs[r].empty() ? "multi-GPU build failed" : msgs[r].c_str());
-    }
+  mb->opts = *opts;
+  mb->opts.devices = mb->devices.data();
+  mb->incremental = job.prev != nullptr;
+  mb->n_items = job.items->n;
+  hny_multi_builder &m = *mb;
+  if (int rc = on_all_ranks(m, [&](int r) { return create_rank(m, r, job); })) return rc; // uploads run in parallel
+  *out = mb.release();
+  return HNY_OK;
+}
+
+int run_multi(hny_multi_builder *mb, hny_graph **out) {
+  *out = nullptr;
+  std::vector<uint64_t> sums(mb->world, 0);
+  int rc = on_all_ranks(*mb, [&](int r) { return run_rank(*mb, r, out, &sums[r]); });
+  mb->ran = true;
+  if (rc) {
+    if (*out) hny_graph_free(*out);
+    *out = nullptr;
+    return rc;
+  }
   if (env_int("HNY_MGPU_VERIFY", 0))
-    for (int r = 1; r < world; r++)
+    for (int r = 1; r < mb->world; r++)
       if (sums[r] != sums[0]) {
         hny_graph_free(*out);
         *out = nullptr;
@@ -387,3 +480,42 @@ extern "C" int hny_internal_build_multi(const hny_build_opts *opts, const hny_it
       }
   return HNY_OK;
 }
+
+} // namespace
+
+extern "C" int hny_internal_build_multi(const hny_build_opts *opts, const hny_items *items, const uint32_t *to_insert,
+                                        uint64_t n_insert, const uint32_t *to_delete, uint64_t n_delete,
+                                        const hny_prev_graph *prev, hny_graph **out) {
+  *out = nullptr;
+  Job job{opts, items, to_insert, to_delete, n_insert, n_delete, prev};
+  hny_multi_builder *mb = nullptr;
+  if (int rc = create_multi(job, &mb)) return rc;
+  std::unique_ptr<hny_multi_builder> guard(mb);
+  return run_multi(mb, out);
+}
+
+// ---- the resident form behind the C ABI (include/hannoy_amd.h)
+extern "C" int hny_multi_builder_create(const hny_build_opts *opts, const hny_items *items, hny_multi_builder **out) {
+  if (!out) return failf(HNY_ERR_INVALID_ARG, "null out");
+  *out = nullptr;
+  if (!opts || !items) return failf(HNY_ERR_INVALID_ARG, "null argument");
+  hny_build_opts o = *opts;
+  if (o.n_gpus < 1) o.n_gpus = 1;
+  Job job{&o, items, nullptr, nullptr, 0, 0, nullptr};
+  return create_multi(job, out);
+}
+extern "C" int hny_multi_builder_run(hny_multi_builder *mb, hny_graph **out) {
+  if (!mb || !out) return failf(HNY_ERR_INVALID_ARG, "null argument");
+  return run_multi(mb, out);
+}
+extern "C" int hny_multi_builder_set_profiling(hny_multi_builder *mb, int on) {
+  if (!mb) return failf(HNY_ERR_INVALID_ARG, "null builder");
+  mb->profiling = on != 0;
+  return HNY_OK;
+}
+extern "C" uint32_t hny_multi_builder_world(const hny_multi_builder *mb) { return mb ? (uint32_t)mb->world : 0u; }
+extern "C" uint64_t hny_multi_builder_collectives(const hny_multi_builder *mb) { return mb ? mb->n_collectives : 0u; }
+extern "C" hny_builder *hny_multi_builder_replica(hny_multi_builder *mb, uint32_t rank) {
+  return mb && rank < (uint32_t)mb->world ? mb->b[rank] : nullptr;
+}
+extern "C" void hny_multi_builder_destroy(hny_multi_builder *mb) { delete mb; }

@@ -47,7 +47,8 @@ enum {
                                   * set of a walk that never evicts outgrew 65 536 entries (4 096 in a
                                   * filtered search), or more than 128 candidates tied with the result
                                   * set's maximum at once (tie pool) — inputs the reference still handles,
-                                  * slowly; nothing has been written, the call can be repeated on the CPU */
+                                  * slowly.  Nothing has been written and no graph is returned; there is no
+                                  * CPU path in this library to repeat the call on */
   HNY_ERR_OOM = -8
 };
 
@@ -224,6 +225,24 @@ uint32_t hny_batch_size(double batch_frac, uint32_t batch_max, uint64_t n_done);
  * least 65 536 (a batch stays the same small fraction of the index as it grows) */
 uint32_t hny_default_batch_max(uint64_t n_items);
 
+/* ---- resident multi-GPU build: replaces the rayon pool of the insert loop (hnsw.rs:172-185 over
+ * src/parallel.rs:11-45) for a caller that builds more than once on the same vectors — the stepwise
+ * counterpart of hny_build(n_gpus > 1), like hny_builder_* is of hny_build.  _create uploads a full
+ * replica of the items to every GPU of opts->devices (NULL: 0 .. n_gpus-1; the uploads run in parallel)
+ * and sets up the RCCL communicator; every _run is one complete fresh build (graph reset -> every batch
+ * sharded across the GPUs, two all-gathers per batch on the builders' streams -> records exported by rank
+ * 0) and returns the bytes hny_build(n_gpus = 1) returns.  Callbacks of `opts` fire on the calling
+ * thread.  Fresh builds only (an incremental build is one-shot: hny_build_incremental). ---- */
+typedef struct hny_multi_builder hny_multi_builder;
+int hny_multi_builder_create(const hny_build_opts *opts, const hny_items *items, hny_multi_builder **out);
+int hny_multi_builder_run(hny_multi_builder *mb, hny_graph **out);
+int hny_multi_builder_set_profiling(hny_multi_builder *mb, int on); /* per-kernel times of rank 0's shard */
+uint32_t hny_multi_builder_world(const hny_multi_builder *mb);       /* replicas = GPUs in use */
+uint64_t hny_multi_builder_collectives(const hny_multi_builder *mb); /* all-gathers of the last run */
+/* the replica of `rank` (library-owned), e.g. for hny_builder_search_knn after a run */
+hny_builder *hny_multi_builder_replica(hny_multi_builder *mb, uint32_t rank);
+void hny_multi_builder_destroy(hny_multi_builder *mb);
+
 /* ---- distances (trait Distance::distance, src/distance/mod.rs:41): pairs of stored items ---- */
 int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot_a,
                           const uint32_t *slot_b, float *out);
@@ -272,15 +291,15 @@ int hny_encode_vectors(int32_t metric, uint32_t dim, uint64_t n, const float *ve
                        void *out_codes, void *out_headers);
 /* the same on the GPU (bulk ingest): bit codecs by ballot, Cosine norms in the reference's x86
  * summation order (simple_avx.rs / simple_sse.rs / scalar) — byte-identical to the host path */
+int hny_encode_vectors_gpu(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
+                           void *out_codes, void *out_headers, int32_t device);
+
 /* Diagnostic: runs the distance kernels' cross-lane primitives (DPP moves, v_permlane16/32_swap) next
  * to the generic __shfl_xor on one wave of `device` (-1 = current).  HNY_OK when every lane agrees;
  * HNY_ERR_DEVICE otherwise, with bit (5 * log2(offset) + check) of mismatch64[lane] set (may be
  * NULL).  No reference counterpart: the reference's reductions are the AVX/SSE horizontal sums of
  * src/spaces/simple_avx.rs:69-110. */
 int hny_selftest_lane_ops(int32_t device, uint32_t *mismatch64);
-
-int hny_encode_vectors_gpu(int32_t metric, uint32_t dim, uint64_t n, const float *vectors,
-                           void *out_codes, void *out_headers, int32_t device);
 
 /* ---- on-disk records (key.rs:54-82, node.rs:130-174, metadata.rs:22-73, version.rs:33-60) ---- */
 typedef int (*hny_kv_sink)(void *ctx, const uint8_t *key, size_t key_len, const uint8_t *val,
@@ -332,6 +351,22 @@ void hny_lmdb_close(hny_lmdb_env *e);
 
 const char *hny_last_error(void);
 const char *hny_version(void);
+
+/* sizeof of every public struct as THIS library was compiled, in the order below — a binding that
+ * declares the structs itself (Rust #[repr(C)], ctypes, cgo) compares them with its own at start-up,
+ * so that a field added here cannot go unnoticed there.  Writes min(n, HNY_ABI_N_STRUCTS) entries,
+ * returns HNY_ABI_N_STRUCTS. */
+enum {
+  HNY_ABI_BUILD_OPTS = 0, /* hny_build_opts */
+  HNY_ABI_ITEMS = 1,      /* hny_items */
+  HNY_ABI_GRAPH = 2,      /* hny_graph */
+  HNY_ABI_PREV_GRAPH = 3, /* hny_prev_graph */
+  HNY_ABI_BATCH = 4,      /* hny_batch */
+  HNY_ABI_QUERY_OPTS = 5, /* hny_query_opts */
+  HNY_ABI_LMDB_STAT = 6,  /* hny_lmdb_stat */
+  HNY_ABI_N_STRUCTS = 7
+};
+uint32_t hny_abi_sizes(uint32_t *out_sizes, uint32_t n);
 
 #ifdef __cplusplus
 }

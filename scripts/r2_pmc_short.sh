@@ -8,7 +8,7 @@ run() { # name
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${name}_f -- python3 bench.py $ARGS > $out/${name}_f.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${name}_w -- python3 bench.py $ARGS > $out/${name}_w.log 2>&1
   python3 scripts/pmc_summary.py $(find $out/${name}_f -name "*counter_collection.csv") $(find $out/${name}_w -name "*counter_collection.csv") $out/$name.json > $out/$name.txt 2>&1
-  tail -1 $out/${name}_f.log > $out/${name}_bench.json
+  grep -a '"metric"' $out/${name}_f.log | tail -1 > $out/${name}_bench.json
   find $out -name "*.csv" -delete
   echo "== $name"; cat $out/$name.txt
 }

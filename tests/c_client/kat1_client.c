@@ -16,7 +16,21 @@ static int sink(void *ctx, const uint8_t *key, size_t kl, const uint8_t *val, si
   return 0;
 }
 
+/* this translation unit's view of the public structs (gcc, C99) against the library's own (hipcc, C++) */
+static int abi_matches(void) {
+  uint32_t s[HNY_ABI_N_STRUCTS];
+  if (hny_abi_sizes(s, HNY_ABI_N_STRUCTS) != HNY_ABI_N_STRUCTS) return 0;
+  return s[HNY_ABI_BUILD_OPTS] == sizeof(hny_build_opts) && s[HNY_ABI_ITEMS] == sizeof(hny_items) &&
+         s[HNY_ABI_GRAPH] == sizeof(hny_graph) && s[HNY_ABI_PREV_GRAPH] == sizeof(hny_prev_graph) &&
+         s[HNY_ABI_BATCH] == sizeof(hny_batch) && s[HNY_ABI_QUERY_OPTS] == sizeof(hny_query_opts) &&
+         s[HNY_ABI_LMDB_STAT] == sizeof(hny_lmdb_stat);
+}
+
 int main(void) {
+  if (!abi_matches()) {
+    fprintf(stderr, "ABI mismatch: struct sizes differ between hannoy_amd.h as compiled here and the library\n");
+    return 3;
+  }
   float vecs[6][2];
   uint32_t ids[6];
   uint8_t levels[6] = {1, 0, 1, 1, 0, 0};

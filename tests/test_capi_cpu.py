@@ -29,6 +29,72 @@ def test_exports_every_declared_symbol(hny):
     assert declared == set(_capi.EXPORTED)
 
 
+def test_abi_struct_sizes_library_vs_bindings(hny, tmp_path):
+    """hny_abi_sizes: sizeof of every public struct as the library was compiled == (1) the ctypes
+    declarations of hannoy_amd/_capi.py, (2) the header compiled as C99 by gcc, (3) the #[repr(C)]
+    structs INTEGRATION.md §2 tells a Rust maintainer to write (parsed from the document, laid out by
+    the C rules: a field missing there hands the library garbage — round 2's defect)."""
+    import subprocess
+    from hannoy_amd import _capi
+    lib_sizes = hny.abi_sizes()
+    assert list(lib_sizes) == [n for n, _ in _capi.ABI_STRUCTS]
+    for name, cls in _capi.ABI_STRUCTS:
+        assert C.sizeof(cls) == lib_sizes[name], name
+    # (2) gcc's view of include/hannoy_amd.h
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "hannoy_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(hny_build_opts),sizeof(hny_items),sizeof(hny_graph),sizeof(hny_prev_graph),'
+                   'sizeof(hny_batch),sizeof(hny_query_opts),sizeof(hny_lmdb_stat));return 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert got == list(lib_sizes.values())
+    # (3) the Rust structs of INTEGRATION.md
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = {"HnyBuildOpts": "hny_build_opts", "HnyItems": "hny_items", "HnyGraph": "hny_graph",
+            "HnyPrevGraph": "hny_prev_graph"}
+
+    def size_align(ty):
+        ty = ty.strip()
+        if ty in ("i32", "u32", "f32", "c_int"):
+            return 4, 4
+        if ty in ("u8", "i8"):
+            return 1, 1
+        if ty in ("u16", "i16"):
+            return 2, 2
+        if ty in ("u64", "i64", "f64", "usize", "isize") or ty.startswith("*") or ty.startswith("Option<extern"):
+            return 8, 8
+        raise AssertionError(f"unknown Rust type in INTEGRATION.md: {ty!r}")
+
+    for rname, cname in rust.items():
+        m = re.search(r"#\[repr\(C\)\] pub struct %s \{(.*?)\}\n" % rname, doc, re.S)
+        assert m, f"INTEGRATION.md lacks #[repr(C)] struct {rname}"
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        # split on the commas between fields (none of the field types nests a comma outside parentheses)
+        fields, depth, cur = [], 0, ""
+        for ch in body:
+            depth += ch in "(<"
+            depth -= ch in ")>" and depth > 0
+            if ch == "," and depth == 0:
+                fields.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        fields.append(cur)
+        off, maxal = 0, 1
+        for f in fields:
+            f = f.strip()
+            if not f:
+                continue
+            assert f.startswith("pub ") and ":" in f, f
+            sz, al = size_align(f.split(":", 1)[1].replace("->", "").strip() if "Option<extern" not in f
+                                else "Option<extern")
+            off = (off + al - 1) // al * al + sz
+            maxal = max(maxal, al)
+        total = (off + maxal - 1) // maxal * maxal
+        assert total == lib_sizes[cname], f"INTEGRATION.md {rname}: {total} bytes, library {cname}: {lib_sizes[cname]}"
+
+
 def test_no_cpu_fallback(hny):
     import torch
     if torch.cuda.is_available():
@@ -45,6 +111,9 @@ def test_no_cpu_fallback(hny):
     with pytest.raises(hny.HannoyError) as e:
         hny.build(items, n_gpus=100)
     assert e.value.code == -1
+    with pytest.raises(hny.HannoyError) as e:  # the resident form (hny_multi_builder_create)
+        hny.MultiBuilder(items, n_gpus=2)
+    assert e.value.code == -6
 
 
 def test_argument_validation(hny):

@@ -1057,6 +1057,55 @@ def test_native_multi_gpu_driver_ranks_share_one_gpu(orc, hny, monkeypatch, worl
         hny.build(items, devices=[0] * world, cancel=lambda: len(seen) > 0, **kw)
 
 
+def test_resident_multi_builder_runs_twice(orc, hny, monkeypatch):
+    """hny_multi_builder_*: replicas created once (two ranks on GPU 0 through the shim), two complete
+    builds on them — both equal the oracle's graph and the one-GPU build's counters; the replica handle
+    searches like a plain builder.  This is what `bench.py --gpus N --native` times."""
+    monkeypatch.setenv("HNY_MGPU_SHIM", "1")
+    monkeypatch.setenv("HNY_MGPU_VERIFY", "1")
+    monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "16")
+    monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
+    ds, items, o, kw = _multi_case(orc, hny)
+    g1 = hny.build(items, **kw)
+    with hny.MultiBuilder(items, devices=[0, 0], **kw) as mb:
+        assert mb.world == 2
+        for _ in range(2):
+            g = mb.run()
+            _same_graph(g, o)
+            assert (g.n_links_added, g.n_evals_walk, g.n_evals_prune, g.n_evals_apply) == \
+                   (g1.n_links_added, g1.n_evals_walk, g1.n_evals_prune, g1.n_evals_apply)
+            assert mb.n_collectives > 0
+        rng = np.random.default_rng(3)
+        qs = rng.uniform(-1, 1, (64, items.dim)).astype(np.float32)
+        qc = orc.encode_vectors(items.metric, qs)
+        qh = orc.make_headers(items.metric, items.dim, qc)
+        for r in (0, 1):
+            ids, dists, counts = mb.replica(r).search_knn(qc, qh, k=5, ef_search=32)
+            oi, od, oc = orc.search(ds, o, qc, qh, k=5, ef_search=32, order=orc.ORDER_WAVE)
+            assert np.array_equal(counts, oc) and np.array_equal(ids, oi) and np.array_equal(dists, od)
+
+
+def test_native_multi_gpu_overflow_in_a_shard_fails_the_build(orc, hny, monkeypatch):
+    """A device-side overflow inside the shard of a rank >= 1 exists only in THAT rank's counter block
+    (rank 0 never walked those members), while its clipped selection is all-gathered into every replica:
+    every rank's error words are folded into the ranks' agreement, so the build fails exactly as it does
+    on one GPU — with HNY_MGPU_VERIFY off, i.e. without the replica comparison that used to mask this."""
+    monkeypatch.setenv("HNY_MGPU_SHIM", "1")
+    monkeypatch.delenv("HNY_MGPU_VERIFY", raising=False)
+    monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "4")
+    monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
+    monkeypatch.setenv("HNY_TEST_POOL_CAP", "4")  # a 4-slot tie pool: the overflow the 128-slot pool needs M0 = 333 for
+    h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
+    metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
+    frac = float(h["frac"][0])
+    ds = orc.Dataset.from_f32(metric, h["mat0"], h["lv0"], h["ids0"])
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    for world in (2, 3):
+        with pytest.raises(hny.HannoyError) as e:
+            hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax, devices=[0] * world)
+        assert e.value.code == -7 and "tie pool overflow" in str(e.value)
+
+
 @pytest.mark.parametrize("M,M0", [(8, 16), (16, 96)])
 def test_native_multi_gpu_driver_incremental(orc, hny, monkeypatch, M, M0):
     """hny_build_incremental through the native driver (two ranks on one GPU): deletes + inserts on
