@@ -4,6 +4,7 @@
 // hny_kernels.hip.  No CPU fallback: without a device every computing entry point fails.
 #include "../../include/hannoy_amd.h"
 #include "hny_internal.h"
+#include "hny_rust_sort.h"
 
 #include <algorithm>
 #include <chrono>
@@ -40,6 +41,12 @@ int fail(int code, const char *fmt, ...) {
 } // namespace
 // error reporting for the other host translation units (hny_lmdb.cpp)
 int hny_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+// HNY_LEVEL_ORDER=id: items of one level inserted in ascending id order (rounds 1-2) instead of the order
+// Rust's sort_unstable_by leaves them in (hny_rust_sort.h)
+static bool level_order_by_id() {
+  const char *e = getenv("HNY_LEVEL_ORDER");
+  return e && (e[0] == 'i' || e[0] == 'I');
+}
 namespace {
 
 double now_s() {
@@ -743,10 +750,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     else
       draw_levels(o.seed, o.M, n, lv.data());
     for (uint32_t s = 0; s < n; s++) levels.push_back({s, lv[s]});
-    std::stable_sort(levels.begin(), levels.end(),
-                     [](const std::pair<uint32_t, uint8_t> &x, const std::pair<uint32_t, uint8_t> &y) {
-                       return x.second > y.second;
-                     });
+    hny_rust_sort::sort_levels(levels, level_order_by_id()); // hnsw.rs:268, ties as the reference leaves them
     b->max_level = n ? levels[0].second : 0;
     for (uint32_t s = 0; s < n; s++)
       if (lv[s] == b->max_level) b->entry_points.push_back(s);
@@ -800,10 +804,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     if (!del_eps.empty() && n_new != n_old) max_level = 0; // :261-263
     for (uint32_t s = 0; s < n; s++)
       if (in_new[s] && !inc->load_only) levels.push_back({s, (uint8_t)max_level}); // :267
-    std::stable_sort(levels.begin(), levels.end(),
-                     [](const std::pair<uint32_t, uint8_t> &x, const std::pair<uint32_t, uint8_t> &y) {
-                       return x.second > y.second;
-                     }); // :268
+    hny_rust_sort::sort_levels(levels, level_order_by_id()); // :268
     if (cur_max > max_level) { // :272-276
       std::fill(in_new.begin(), in_new.end(), 0);
       max_level = cur_max;

@@ -870,7 +870,25 @@ struct ChaCha12 {
 };
 } // namespace
 
+static void draw_levels_impl(const uint8_t *seed32, uint64_t seed_u64, uint64_t skip, uint32_t M, uint64_t n,
+                             uint8_t *out);
 void orc_draw_levels(const uint8_t *seed32, uint64_t seed_u64, uint32_t M, uint64_t n, uint8_t *out) {
+  draw_levels_impl(seed32, seed_u64, 0, M, n, out);
+}
+void orc_draw_levels_skip(const uint8_t *seed32, uint64_t skip, uint32_t M, uint64_t n, uint8_t *out) {
+  draw_levels_impl(seed32, 0, skip, M, n, out);
+}
+/* rng.gen::<f32>() (rand 0.8.5 Standard, float_impls: 24 random bits times 2^-24) from
+ * StdRng::from_seed(seed32) after `skip` u32 words — the generator of the reference's random test
+ * vectors (src/tests/writer.rs:137) */
+void orc_gen_f32(const uint8_t *seed32, uint64_t skip, uint64_t n, float *out) {
+  ChaCha12 rng;
+  std::memcpy(rng.key, seed32, 32);
+  for (uint64_t i = 0; i < skip; i++) (void)rng.next_u32();
+  for (uint64_t i = 0; i < n; i++) out[i] = (float)(rng.next_u32() >> 8) * (1.0f / 16777216.0f);
+}
+static void draw_levels_impl(const uint8_t *seed32, uint64_t seed_u64, uint64_t skip, uint32_t M, uint64_t n,
+                             uint8_t *out) {
   uint8_t seed[32];
   if (seed32) {
     std::memcpy(seed, seed32, 32);
@@ -886,6 +904,7 @@ void orc_draw_levels(const uint8_t *seed32, uint64_t seed_u64, uint32_t M, uint6
   }
   ChaCha12 rng;
   std::memcpy(rng.key, seed, 32);
+  for (uint64_t i = 0; i < skip; i++) (void)rng.next_u32();
   float probas[64];
   uint32_t np = orc_level_probas(M, probas, 64);
   /* WeightedIndex::new: running totals before each further weight; Uniform::new(0, total) */
@@ -915,6 +934,154 @@ void orc_draw_levels(const uint8_t *seed32, uint64_t seed_u64, uint32_t M, uint6
   }
 }
 
+/* [3P] `levels.sort_unstable_by(|(_, a), (_, b)| b.cmp(a))` (hnsw.rs:268) as Rust's standard library
+ * performs it since 1.81 (core::slice::sort::unstable: ipnsort) on `(u32, usize)` pairs — restated from
+ * the published algorithm, because the order it leaves EQUAL levels in decides the insertion order and
+ * with it the graph (the reference's 100-point snapshots, KAT-9).  Only the steps that can reorder equal
+ * elements are spelled out: the existing-run check, the pivot choice (median of 3, recursive from 64
+ * elements), the branchless cyclic Lomuto partition and the quicksort driver with its equal-to-ancestor
+ * partition.  Slices of <= 32 elements go to the library's small-sort (sorting networks on 8 + insertion
+ * + bidirectional merge for 16-byte elements): every step of it is stable, so a stable sort stands in.
+ * <= 20 elements: insertion sort (stable).  The heapsort fallback (after 2 * ilog2(n) unbalanced
+ * partitions) is restated too but never reached by level data (a handful of distinct keys), hence unpinned. */
+namespace {
+typedef std::pair<uint32_t, uint32_t> LevelPair; /* (slot or id, level) */
+struct RustSort {
+  /* is_less(a, b) of the comparator |a, b| b.level.cmp(a.level) == Less  <=>  b.level < a.level */
+  static bool lt(const LevelPair &a, const LevelPair &b) { return b.second < a.second; }
+  static void small_sort(LevelPair *v, size_t n) {
+    std::stable_sort(v, v + n, [](const LevelPair &a, const LevelPair &b) { return lt(a, b); });
+  }
+  static size_t median3(const LevelPair *v, size_t a, size_t b, size_t c) {
+    const bool x = lt(v[a], v[b]), y = lt(v[a], v[c]);
+    if (x == y) {
+      const bool z = lt(v[b], v[c]);
+      return (z ^ x) ? c : b;
+    }
+    return a;
+  }
+  static size_t median3_rec(const LevelPair *v, size_t a, size_t b, size_t c, size_t n) {
+    if (n * 8 >= 64) {
+      const size_t n8 = n / 8;
+      a = median3_rec(v, a, a + n8 * 4, a + n8 * 7, n8);
+      b = median3_rec(v, b, b + n8 * 4, b + n8 * 7, n8);
+      c = median3_rec(v, c, c + n8 * 4, c + n8 * 7, n8);
+    }
+    return median3(v, a, b, c);
+  }
+  static size_t choose_pivot(const LevelPair *v, size_t len) {
+    const size_t d = len / 8, a = 0, b = d * 4, c = d * 7;
+    return len < 64 ? median3(v, a, b, c) : median3_rec(v, a, b, c, d);
+  }
+  /* partition_lomuto_branchless_cyclic over v[1..len) with the pivot swapped to v[0] */
+  /* less_or_equal: the `|a, b| !is_less(b, a)` form of the equal-to-ancestor partition */
+  static size_t partition(LevelPair *v, size_t len, size_t pivot_pos, bool less_or_equal) {
+    auto less = [less_or_equal](const LevelPair &a, const LevelPair &b) { return less_or_equal ? !lt(b, a) : lt(a, b); };
+    std::swap(v[0], v[pivot_pos]);
+    const LevelPair pivot = v[0];
+    LevelPair *w = v + 1;
+    const size_t n = len - 1;
+    size_t num_lt = 0;
+    if (n) {
+      const LevelPair gap_value = w[0];
+      size_t gap = 0;
+      for (size_t right = 1; right < n; right++) {
+        const bool r_lt = less(w[right], pivot);
+        w[gap] = w[num_lt];
+        w[num_lt] = w[right];
+        gap = right;
+        num_lt += r_lt ? 1 : 0;
+      }
+      const bool r_lt = less(gap_value, pivot);
+      w[gap] = w[num_lt];
+      w[num_lt] = gap_value;
+      num_lt += r_lt ? 1 : 0;
+    }
+    std::swap(v[0], v[num_lt]);
+    return num_lt;
+  }
+  static void quicksort(LevelPair *v, size_t len, const LevelPair *ancestor, uint32_t limit) {
+    for (;;) {
+      if (len <= 32) {
+        small_sort(v, len);
+        return;
+      }
+      if (limit == 0) { /* heapsort::heapsort after 2 * ilog2(n) unbalanced partitions (not reached by level data) */
+        for (size_t i = len + len / 2; i-- > 0;) {
+          size_t node;
+          if (i >= len) {
+            node = i - len;
+          } else {
+            std::swap(v[0], v[i]);
+            node = 0;
+          }
+          const size_t hl = std::min(i, len);
+          for (;;) { /* sift_down */
+            size_t child = 2 * node + 1;
+            if (child >= hl) break;
+            if (child + 1 < hl && lt(v[child], v[child + 1])) child++;
+            if (!lt(v[node], v[child])) break;
+            std::swap(v[node], v[child]);
+            node = child;
+          }
+        }
+        return;
+      }
+      limit--;
+      const size_t pp = choose_pivot(v, len);
+      if (ancestor && !lt(*ancestor, v[pp])) {
+        const size_t num_le = partition(v, len, pp, true);
+        v += num_le + 1;
+        len -= num_le + 1;
+        ancestor = nullptr;
+        continue;
+      }
+      const size_t num_lt = partition(v, len, pp, false);
+      quicksort(v, num_lt, ancestor, limit);
+      ancestor = v + num_lt; /* the pivot, in its final place */
+      v += num_lt + 1;
+      len -= num_lt + 1;
+    }
+  }
+  static void sort(std::vector<LevelPair> &vec) {
+    LevelPair *v = vec.data();
+    const size_t len = vec.size();
+    if (len < 2) return;
+    if (len <= 20) { /* insertion_sort_shift_left: stable */
+      small_sort(v, len);
+      return;
+    }
+    /* find_existing_run: a fully sorted (or strictly descending) input is returned as is (reversed) */
+    size_t run = 2;
+    const bool desc = lt(v[1], v[0]);
+    if (desc) while (run < len && lt(v[run], v[run - 1])) run++;
+    else while (run < len && !lt(v[run], v[run - 1])) run++;
+    if (run == len) {
+      if (desc) std::reverse(vec.begin(), vec.end());
+      return;
+    }
+    uint32_t lg = 0;
+    for (size_t x = len | 1; x > 1; x >>= 1) lg++;
+    quicksort(v, len, nullptr, 2 * lg);
+  }
+};
+/* orc_opts.level_sort: 0 = ties in ascending id order (stable); 1 = Rust >= 1.81 sort_unstable_by */
+void sort_levels(std::vector<LevelPair> &v, int32_t level_sort) {
+  if (level_sort == 1) RustSort::sort(v);
+  else std::stable_sort(v.begin(), v.end(), [](const LevelPair &a, const LevelPair &b) { return a.second > b.second; });
+}
+} // namespace
+
+void orc_rust_sort_levels(uint32_t *ids, uint32_t *levels, uint64_t n) {
+  std::vector<LevelPair> v(n);
+  for (uint64_t i = 0; i < n; i++) v[i] = {ids[i], levels[i]};
+  RustSort::sort(v);
+  for (uint64_t i = 0; i < n; i++) {
+    ids[i] = v[i].first;
+    levels[i] = v[i].second;
+  }
+}
+
 int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
   if (!opts || !items || !out) return -1;
   if (opts->M == 0 || opts->M0 < opts->M) return -2;
@@ -935,9 +1102,12 @@ int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
   /* hnsw.rs:268 sort by level desc. The reference's sort is unstable; ties are taken in
    * ascending id order here (= the order KAT-1 implies for small inputs). */
   std::vector<uint32_t> order(n);
-  for (uint32_t s = 0; s < n; s++) order[s] = s;
-  std::stable_sort(order.begin(), order.end(),
-                   [&](uint32_t a, uint32_t b) { return B.level[a] > B.level[b]; });
+  {
+    std::vector<LevelPair> lv(n);
+    for (uint32_t s = 0; s < n; s++) lv[s] = {s, B.level[s]};
+    sort_levels(lv, opts->level_sort);
+    for (uint32_t s = 0; s < n; s++) order[s] = lv[s].first;
+  }
 
   if (n > 0) {
     B.max_level = cur_max; /* :272-276 fresh DB: max_level starts at 0 */
@@ -1110,10 +1280,7 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
   if (!del_eps.empty() && n_new != n_old) max_level = 0; /* :261-263 */
   for (uint32_t s = 0; s < n; s++)
     if (in_new[s]) levels.push_back({s, max_level}); /* :267 re-index the old entry points */
-  std::stable_sort(levels.begin(), levels.end(),
-                   [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
-                     return a.second > b.second;
-                   }); /* :268 (unstable in Rust; stable == what small inputs get) */
+  sort_levels(levels, opts->level_sort); /* :268 (unstable in Rust; stable == what inputs of <= 20 pairs get) */
   if (cur_max_level > max_level) { /* :272-276 */
     std::fill(in_new.begin(), in_new.end(), 0);
     max_level = cur_max_level;

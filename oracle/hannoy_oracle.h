@@ -14,9 +14,11 @@
  * restated (orc_draw_levels) and pinned by the level sequence the KAT-1 / KAT-5
  * snapshots imply for StdRng::from_seed([42; 32]).  **Parity unpinned** (no
  * golden bytes in the reference): roaring 0.10.9 serialisation (public
- * RoaringFormatSpec followed), heed/LMDB file format (not produced), and the
- * order Rust's sort_unstable_by leaves equal levels in for n > 20 (hnsw.rs:268;
- * ascending id is used).
+ * RoaringFormatSpec followed), heed/LMDB file format (not produced).  The order
+ * Rust's sort_unstable_by leaves equal levels in for n > 20 (hnsw.rs:268) is
+ * restated (orc_opts.level_sort = 1) and pinned by KAT-9, the reference's
+ * 100 x 30 snapshots; level_sort = 0 (ascending id) stays the default of the
+ * GPU-parity tests, because the product orders ties by id.
  *
  * All file:line citations are relative to /root/reference/.
  */
@@ -61,6 +63,11 @@ typedef struct {
    * means plain sequential insertion (the reference with one thread). */
   double batch_frac;
   uint32_t batch_max;
+  /* hnsw.rs:268 `levels.sort_unstable_by(level desc)`: the order equal levels are left in.
+   * 0 = ascending id (a stable sort; what Rust itself produces for <= 20 pairs: insertion sort);
+   * 1 = Rust >= 1.81's sort_unstable_by (ipnsort) restated — pinned by KAT-9, the reference's
+   *     100-point snapshots (src/tests/writer.rs:130-155), which only this order reproduces. */
+  int32_t level_sort;
 } orc_opts;
 
 typedef struct {
@@ -105,6 +112,13 @@ uint32_t orc_level_probas(uint32_t M, float *out, uint32_t cap);
  * KAT-1 / KAT-5 imply for StdRng::from_seed([42; 32]) with M = 3.  seed32 != NULL: from_seed(seed32);
  * else seed_from_u64(seed_u64) (python.rs:261).  skip = u32 words already consumed. */
 void orc_draw_levels(const uint8_t *seed32, uint64_t seed_u64, uint32_t M, uint64_t n, uint8_t *out);
+/* the same from StdRng::from_seed(seed32) after `skip` u32 words of the same generator */
+void orc_draw_levels_skip(const uint8_t *seed32, uint64_t skip, uint32_t M, uint64_t n, uint8_t *out);
+/* rng.gen::<f32>() x n from StdRng::from_seed(seed32) after `skip` words (rand 0.8.5 Standard) — pinned
+ * by the 1 000 + 500 vector components the KAT-9 snapshots print */
+void orc_gen_f32(const uint8_t *seed32, uint64_t skip, uint64_t n, float *out);
+/* hnsw.rs:268 as Rust >= 1.81 sorts it (see orc_opts.level_sort), in place on parallel arrays */
+void orc_rust_sort_levels(uint32_t *ids, uint32_t *levels, uint64_t n);
 
 /* ---- build (hnsw.rs:122-216, fresh DB) ---- */
 int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out);

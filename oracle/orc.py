@@ -37,7 +37,8 @@ class QueryOpts(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("metric", C.c_int32), ("dim", C.c_uint32), ("M", C.c_uint32), ("M0", C.c_uint32),
                 ("ef_construction", C.c_uint32), ("alpha", C.c_float), ("order", C.c_int32),
-                ("threads", C.c_int32), ("batch_frac", C.c_double), ("batch_max", C.c_uint32)]
+                ("threads", C.c_int32), ("batch_frac", C.c_double), ("batch_max", C.c_uint32),
+                ("level_sort", C.c_int32)]
 
 
 class Items(C.Structure):
@@ -289,9 +290,42 @@ class Graph:
         return out
 
 
+LEVEL_SORT_BY_ID, LEVEL_SORT_RUST = 0, 1  # orc_opts.level_sort (hnsw.rs:268)
+
+
 def make_opts(metric, dim, M=16, M0=32, ef=100, alpha=1.0, order=ORDER_X86, threads=1,
-              batch_frac=0.0, batch_max=0):
-    return Opts(metric, dim, M, M0, ef, alpha, order, threads, batch_frac, batch_max)
+              batch_frac=0.0, batch_max=0, level_sort=LEVEL_SORT_RUST):
+    return Opts(metric, dim, M, M0, ef, alpha, order, threads, batch_frac, batch_max, level_sort)
+
+
+def gen_f32(seed32, skip, n):
+    """rng.gen::<f32>() x n from StdRng::from_seed(seed32) after `skip` u32 words (orc_gen_f32)"""
+    out = np.zeros(n, np.float32)
+    seed = (C.c_uint8 * 32).from_buffer_copy(bytes(seed32))
+    L = lib()
+    L.orc_gen_f32.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.orc_gen_f32(seed, skip, n, _p(out))
+    return out
+
+
+def draw_levels_skip(seed32, skip, M, n):
+    """get_random_level x n from StdRng::from_seed(seed32) after `skip` u32 words"""
+    out = np.zeros(n, np.uint8)
+    seed = (C.c_uint8 * 32).from_buffer_copy(bytes(seed32))
+    L = lib()
+    L.orc_draw_levels_skip.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
+    L.orc_draw_levels_skip(seed, skip, M, n, _p(out))
+    return out
+
+
+def rust_sort_levels(ids, levels):
+    """hnsw.rs:268 as Rust >= 1.81 sorts (id, level) pairs by level descending (orc_rust_sort_levels)"""
+    i = np.ascontiguousarray(ids, np.uint32).copy()
+    lv = np.ascontiguousarray(levels, np.uint32).copy()
+    L = lib()
+    L.orc_rust_sort_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.orc_rust_sort_levels(_p(i), _p(lv), len(i))
+    return i, lv
 
 
 def build(ds, **kw):

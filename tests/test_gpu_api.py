@@ -505,3 +505,38 @@ def test_graph_write_lmdb_equals_record_stream(H, tmp_path):
         assert env.items() == recs
         k, v = recs[-1]
         assert env.get(k) == v and len(v) == 1 + 4 + 3072
+
+
+def test_write_and_update_lot_of_random_points_with_snapshot(H, orc):
+    """src/tests/writer.rs:130-155 with its two insta snapshots (tests/golden/kat9_100x30.json), through the
+    Writer API: one StdRng::from_seed([42; 32]) feeds the 100 random vectors, the level draws of the first
+    build, the 50 replacement vectors and the level draws of the second build; `build::<3, 3>` in strict mode
+    with one insertion at a time (the reference's test pins one rayon thread) must leave exactly the Links
+    records, entry points and max_level of the two dumps."""
+    import json
+    import os
+    from tests.test_oracle_kat import kat9_inputs
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kat9_100x30.json")) as f:
+        k = json.load(f)
+    v1, lv1, upd, v2, lv2 = kat9_inputs(orc, k)  # rng.gen::<f32>() restated in the oracle, checked against the dumps
+    rng = _rng42(H)
+    db = H.Database(None, H.Metric.EUCLIDEAN)
+    w = db.writer(k["dim"])
+    for i in range(k["n"]):
+        w.add_item(i, v1[i])
+    rng.drawn += k["n"] * k["dim"]  # what `std::array::from_fn(|_| rng.gen())` took from the generator
+    w.builder(rng).build(3, 3, batch_max=1, x86_order=True)
+    m = db.metadata(0)
+    assert (m["entry_points"].tolist(), m["max_level"]) == (k["fresh"]["entry_points"], k["fresh"]["max_level"])
+    assert _dump_links(db) == k["fresh"]["links"]
+    w = db.writer(k["dim"])
+    for j, i in enumerate(upd):
+        w.add_item(int(i), v2[int(i)])
+    rng.drawn += len(upd) * k["dim"]
+    w.builder(rng).build(3, 3, batch_max=1, x86_order=True)
+    m = db.metadata(0)
+    assert (m["entry_points"].tolist(), m["max_level"]) == (k["updated"]["entry_points"], k["updated"]["max_level"])
+    assert _dump_links(db) == k["updated"]["links"]
+    r = db.reader(0)
+    r.assert_validity()
+    r.close()

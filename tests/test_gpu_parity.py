@@ -1094,7 +1094,6 @@ def test_native_multi_gpu_overflow_in_a_shard_fails_the_build(orc, hny, monkeypa
     monkeypatch.delenv("HNY_MGPU_VERIFY", raising=False)
     monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "4")
     monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
-    monkeypatch.setenv("HNY_TEST_POOL_CAP", "4")  # a 4-slot tie pool: the overflow the 128-slot pool needs M0 = 333 for
     h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
     metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
     frac = float(h["frac"][0])
@@ -1275,3 +1274,38 @@ def test_m0_limits_are_refused_loudly(orc, hny):
         with pytest.raises(hny.HannoyError) as e:
             hny.build(items, ef_construction=32, **kw)
         assert e.value.code == -5
+
+
+def test_kat9_reference_snapshots_on_the_gpu(orc, hny):
+    """KAT-9 through the C ABI: strict mode (x86 summation order: SSE path at dim 30) with batch_max = 1 is
+    the reference run with one thread, so hny_build must return the 167 Links records of the reference's
+    own 100 x 30 snapshot (src/tests/writer.rs:130-155) and hny_build_incremental the 192 records of the
+    second one — levels drawn by the PRODUCT's restated StdRng (3 000 words into the stream, as the test's
+    generator is), insertion order = what Rust's sort_unstable_by leaves (hny_rust_sort.h).  The default
+    (batch-synchronous, wave order) build of the same inputs equals the oracle's."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kat9_100x30.json")) as f:
+        k = json.load(f)
+    from tests.test_oracle_kat import kat9_inputs
+    v1, lv1, upd, v2, lv2 = kat9_inputs(orc, k)
+    rng = hny.StdRng.from_seed(bytes(k["seed"]))
+    rng.drawn = k["n"] * k["dim"]                       # the 3 000 f32 the vectors took
+    assert rng.draw_levels(k["M"], k["n"]).tolist() == lv1.tolist()
+    rng.drawn += len(upd) * k["dim"]
+    assert rng.draw_levels(k["M"], len(upd)).tolist() == lv2.tolist()
+
+    def links_of(g):
+        return [[int(i), int(l), nb] for (i, l), nb in sorted(g.as_dict().items())]
+    kw = dict(M=k["M"], M0=k["M0"], ef_construction=k["ef_construction"])
+    ds1, it1 = _mk(orc, hny, 1, v1, lv1)
+    g1 = hny.build(it1, batch_max=1, x86_order=True, **kw)
+    assert g1.entry_points.tolist() == k["fresh"]["entry_points"] and g1.max_level == k["fresh"]["max_level"]
+    assert links_of(g1) == k["fresh"]["links"]
+    ds2 = orc.Dataset.from_f32(1, v2, np.zeros(k["n"], np.uint8))
+    it2 = hny.ItemSet(1, k["dim"], ds2.ids, ds2.codes, ds2.headers, lv2)
+    g2 = hny.build_incremental(it2, g1, upd, [], batch_max=1, x86_order=True, **kw)
+    assert g2.entry_points.tolist() == k["updated"]["entry_points"] and g2.max_level == k["updated"]["max_level"]
+    assert links_of(g2) == k["updated"]["links"]
+    # default schedule and wave order: same insertion order on both sides -> the oracle's graph
+    o = orc.build(ds1, M=k["M"], M0=k["M0"], ef=k["ef_construction"], order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=65536)
+    _same_graph(hny.build(it1, **kw), o)

@@ -169,3 +169,74 @@ def test_level_rng_reproduces_reference_draws(kat, orc):
     lv = orc.draw_levels(16, 200000, seed_u64=42)
     frac0 = np.mean(lv == 0)
     assert abs(frac0 - 15 / 16) < 0.003 and lv.max() <= 7
+
+
+@pytest.fixture(scope="module")
+def kat9():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kat9_100x30.json")) as f:
+        return json.load(f)
+
+
+def kat9_inputs(orc, k):
+    """The inputs of src/tests/writer.rs:130-155, regenerated: 100 x 30 `rng.gen::<f32>()` from
+    StdRng::from_seed([42; 32]), the 100 level draws of the first build (the same generator goes on), the
+    50 x 30 replacement vectors, the 50 level draws of the second build — every printed component and every
+    level the snapshots imply is checked."""
+    seed, n, dim = bytes(k["seed"]), k["n"], k["dim"]
+    v1 = orc.gen_f32(seed, 0, n * dim).reshape(n, dim)
+    lv1 = orc.draw_levels_skip(seed, n * dim, k["M"], n)
+    upd = np.array(k["updated_ids"], np.uint32)
+    v2 = v1.copy()
+    v2[upd] = orc.gen_f32(seed, n * dim + n, len(upd) * dim).reshape(len(upd), dim)
+    lv2 = orc.draw_levels_skip(seed, n * dim + n + len(upd) * dim, k["M"], len(upd))
+    for vecs, snap in ((v1, k["fresh"]), (v2, k["updated"])):
+        for i in range(n):
+            printed = snap["printed"][str(i)]
+            assert ["%.4f" % x for x in vecs[i, :len(printed)]] == printed, i
+    return v1, lv1, upd, v2, lv2
+
+
+def test_kat9_rng_reproduces_the_snapshot_inputs(orc, kat9):
+    """[3P] rand 0.8.5 `Standard` f32 (24 bits x 2^-24) on the restated ChaCha12: the 1 000 + 1 000 vector
+    components the two snapshots print, and the level of all 100 items of the first build (an item's level
+    = its number of Links records - 1) — a 100-draw pin of WeightedIndex<f32> at stream position 3 000."""
+    v1, lv1, upd, v2, lv2 = kat9_inputs(orc, kat9)
+    n_rec = np.zeros(kat9["n"], np.int64)
+    for item, layer, _ in kat9["fresh"]["links"]:
+        n_rec[item] = max(n_rec[item], layer + 1)
+    assert (lv1.astype(np.int64) + 1 == n_rec).all()
+    assert lv1.max() == kat9["fresh"]["max_level"] == 6
+    # after the update an item owns max(old, new) + 1 records: new levels never exceed what the second dump shows
+    n_rec2 = np.zeros(kat9["n"], np.int64)
+    for item, layer, _ in kat9["updated"]["links"]:
+        n_rec2[item] = max(n_rec2[item], layer + 1)
+    assert (np.maximum(lv1[upd], lv2).astype(np.int64) + 1 == n_rec2[upd]).all()
+
+
+def test_kat9_100x30_snapshots(orc, kat9):
+    """KAT-9, the reference's largest live graph fixture: 100 x 30-d Euclidean (the SSE summation path,
+    16 <= dim < 32, src/spaces/simple.rs:19-47), M = M0 = 3, seven levels, one thread — the oracle in the
+    x86 order reproduces the fresh build's 167 Links records and, after the 50-item overwrite, all 192
+    records of the second snapshot, given the order Rust's sort_unstable_by (hnsw.rs:268, ipnsort) leaves
+    equal levels in.  With ids ascending inside a level (a stable sort) 93 of the 167 records differ: the
+    order is part of the reference's result."""
+    k = kat9
+    v1, lv1, upd, v2, lv2 = kat9_inputs(orc, k)
+    kw = dict(M=k["M"], M0=k["M0"], ef=k["ef_construction"], order=orc.ORDER_X86)
+    ds1 = orc.Dataset.from_f32(orc.EUCLIDEAN, v1, lv1)
+    g1 = orc.build(ds1, level_sort=orc.LEVEL_SORT_RUST, **kw)
+    assert g1.entry_points.tolist() == k["fresh"]["entry_points"] and g1.max_level == k["fresh"]["max_level"]
+    assert _links_of(g1) == k["fresh"]["links"]
+    ds2 = orc.Dataset.from_f32(orc.EUCLIDEAN, v2, np.zeros(k["n"], np.uint8))
+    g2 = orc.build_incremental(ds2, g1, upd, lv2, [], level_sort=orc.LEVEL_SORT_RUST, **kw)
+    assert g2.entry_points.tolist() == k["updated"]["entry_points"] and g2.max_level == k["updated"]["max_level"]
+    assert _links_of(g2) == k["updated"]["links"]
+    # the control: same inputs, ties by ascending id
+    g1s = orc.build(ds1, level_sort=orc.LEVEL_SORT_BY_ID, **kw)
+    assert sum(a != b for a, b in zip(_links_of(g1s), k["fresh"]["links"])) > 50
+    # and the first pairs of the order itself: the entry point first, then levels descending
+    ids, lv = orc.rust_sort_levels(np.arange(k["n"]), lv1)
+    assert ids[0] == 65 and (np.diff(lv.astype(np.int64)) <= 0).all() and sorted(ids.tolist()) == list(range(k["n"]))
+    assert ids.tolist() != sorted(ids.tolist(), key=lambda i: (-int(lv1[i]), i))
