@@ -307,7 +307,9 @@ def main():
                         the walk moves beyond the rows (lists, visited sets).
         achieved = min(algorithmic, counted) / time: useful bytes that really crossed the fabric, never
         above what the memory system delivered; frac = achieved / 8 TB/s."""
-        wb = g.n_evals_walk * bytes_per_eval
+        # N > 1: one GPU's share — rank 0's own walks over rank 0's k_walk time (one process per GPU: the
+        # counters of rank 0's graph ARE its shard; --native sums the shards, so the average share is used)
+        wb = g.n_evals_walk * bytes_per_eval / (a.gpus if a.native else 1)
         if g.t_walk_kernels_s <= 0:
             return None
         launches = max(1, int(g.n_walk_launches))
@@ -318,6 +320,8 @@ def main():
              "achieved_algorithmic": round(alg, 1), "frac_algorithmic": round(alg / HBM_PEAK_GBS, 4),
              "launches": launches, "avg_launch_ms": round(1e3 * g.t_walk_kernels_s / launches, 4),
              "algorithmic_bytes_per_launch": int(wb / launches), "bytes_per_eval": bytes_per_eval}
+        if a.gpus > 1:
+            r["scope"] = "one GPU's shard of the walks (rank 0)"
         if steps:  # the same bytes over the WHOLE step (prune, link ops, export included)
             r["frac_whole_build"] = round(wb / (dt_ / steps) / 1e9 / HBM_PEAK_GBS, 4)
         pmc_name, pj = pmc_profile(data_kind)

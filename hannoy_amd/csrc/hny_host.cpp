@@ -1956,7 +1956,10 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
   HIP_TRY(sc.init(qo));
   if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   const uint32_t ef = std::max(ef_search, k); // reader.rs:746
-  if (ef + 1 > b->rcap && ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
+  // result sets of up to 4 096 entries live in the walk's LDS, larger ones in HBM (WalkArgs.res_global, the
+  // general kernel): the reference's own tests search with ef_search = n up to 9 999 (src/tests/reader.rs:82-98)
+  if ((uint64_t)ef + 1 > HNY_RES_GLOBAL_MAX)
+    return fail(HNY_ERR_UNSUPPORTED, "ef_search %u: result sets hold at most %u entries", ef, HNY_RES_GLOBAL_MAX - 1);
   HIP_TRY(hipSetDevice(b->device));
   if (b->n == 0) {
     for (uint64_t i = 0; i < nq; i++) out_counts[i] = 0; // reader.rs:652-654
@@ -1972,6 +1975,9 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
   if (qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
   uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
+  chunk = (uint32_t)std::min<uint64_t>(chunk, std::max<uint64_t>(nq, 1)); // buffers are sized chunk x rcap / k
+  // at most ~2 GB of candidate lists per chunk
+  chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunk, ((uint64_t)2 << 30) / ((uint64_t)std::max(rcap, k) * 8)));
   DevBuf<unsigned char> dq;
   DevBuf<float> dqn;
   DevBuf<u64> dcand, dres; // dres: result sets beyond the LDS (a search from more entry points than ef, res_capacity)
@@ -2107,7 +2113,8 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
                            out_counts, qo);
   if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   const uint32_t k = qo->k, ef = std::max(qo->ef_search, k); // reader.rs:746, 837
-  if (ef > HNY_MAX_EF) return fail(HNY_ERR_UNSUPPORTED, "ef_search too large");
+  if (ef + 1 > HNY_RES_LDS_MAX) // the filtered search keeps its result set in LDS
+    return fail(HNY_ERR_UNSUPPORTED, "ef_search %u with a candidates filter / by_item: at most %u", ef, HNY_RES_LDS_MAX - 1);
   HIP_TRY(hipSetDevice(b->device));
   const uint32_t n = b->n;
   auto exists = [&](uint32_t s) { return !b->incremental || !b->deleted[s]; };
@@ -2152,7 +2159,9 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
   const uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes);
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
   if (!by_item && qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
-  const uint32_t chunk = std::max<uint32_t>(b->max_batch, 256);
+  const uint32_t chunk = (uint32_t)std::max<uint64_t>(
+      1, std::min<uint64_t>(std::min<uint64_t>(std::max<uint32_t>(b->max_batch, 256), std::max<uint64_t>(nq, 1)),
+                            ((uint64_t)2 << 30) / ((uint64_t)std::max(rcap, k) * 8))); // <= ~2 GB of candidate lists
   const bool has_norm = b->g.norms != nullptr;
   DevBuf<unsigned char> dq;
   DevBuf<float> dqn;
