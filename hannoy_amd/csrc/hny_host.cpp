@@ -283,6 +283,11 @@ struct hny_builder {
   // retry counters of a search call (3 words per walk launch)
   DevBuf<u32> d_vtab, d_ctr;
   DevBuf<u64> d_retry;
+  // k_walk_heap (walk_layer on heaps in HBM) for the members whose walk overflowed its tie pool: the list
+  // of those members, a (count, work counter) pair per walk launch of a search call, the heaps
+  DevBuf<u32> d_pool_retry, d_pool_ctr;
+  DevBuf<u64> d_heap_c, d_heap_r;
+  uint32_t heap_grid = 0, heap_c_cap = 0, heap_r_cap = 0, pool_ctr_used = 0;
   uint32_t sub_blocks = 0, vtab_slots = 0, ctr_used = 0;
   bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
@@ -995,6 +1000,18 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     }
     HIP_TRY(b->d_ctr.alloc(3 * 32));
   }
+  {
+    // walk_layer on heaps (k_walk_heap): `candidates` never holds more than the items visited, `res` no more
+    // than a candidate row; as many blocks as ~1 GB of heaps allow
+    b->heap_c_cap = (uint32_t)std::min<uint64_t>((uint64_t)n + 1 + eps_cap_of(b.get()), (uint64_t)1 << 22);
+    b->heap_r_cap = b->rcap + 1;
+    const uint64_t per_block = ((uint64_t)b->heap_c_cap + b->heap_r_cap) * 8;
+    b->heap_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(slots, 512), ((uint64_t)1 << 30) / per_block));
+    HIP_TRY(b->d_heap_c.alloc((size_t)b->heap_grid * b->heap_c_cap));
+    HIP_TRY(b->d_heap_r.alloc((size_t)b->heap_grid * b->heap_r_cap));
+    HIP_TRY(b->d_pool_retry.alloc(cand_rows));
+    HIP_TRY(b->d_pool_ctr.alloc(2 * 64));
+  }
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(b->d_deferred_b.alloc(b->max_ops));
   {
@@ -1220,10 +1237,11 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   HIP_TRY(hipMemsetAsync(queues, 0, (16 + 8 * 16) * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_ctr.p, 0, b->d_ctr.n * 4, b->stream));
   b->ctr_used = 0;
+  HIP_TRY(hipMemsetAsync(b->d_pool_ctr.p, 0, b->d_pool_ctr.n * 4, b->stream));
+  b->pool_ctr_used = 0;
   // one walk launch: rows <= 512 B go to the four-queries-per-wave kernel first, and the one-wave
   // kernel then takes the members it gave up on (none, normally) from the retry list
-  auto launch_walk = [&](WalkArgs w, hipStream_t st) -> hipError_t {
-    w.key_base = w.lo;
+  auto launch_walk_fast = [&](WalkArgs w, hipStream_t st) -> hipError_t {
     const uint32_t n = w.hi - w.lo;
     const int rc = b->sub_blocks && b->ctr_used + 3 <= b->d_ctr.n ? hnyk_walk_sub_rc(b->g, w, b->shape) : 0;
     if (!rc) return hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
@@ -1247,6 +1265,32 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     r.perm = b->d_retry.p;
     r.queue = ctr + 2;
     return hnyk_walk(b->g, r, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
+  };
+  // one walk launch + its safety net: the members whose tie pool overflowed (none, normally) are listed on
+  // the device and walked again by k_walk_heap, which reads the count itself — no host round trip
+  auto launch_walk = [&](WalkArgs w, hipStream_t st) -> hipError_t {
+    w.key_base = w.lo;
+    if (b->pool_ctr_used + 2 > b->d_pool_ctr.n) { // (more walk launches in one search call than counter pairs)
+      hipError_t e = hipMemsetAsync(b->d_pool_ctr.p, 0, b->d_pool_ctr.n * 4, st);
+      if (e != hipSuccess) return e;
+      b->pool_ctr_used = 0;
+    }
+    u32 *pc = b->d_pool_ctr.p + b->pool_ctr_used;
+    b->pool_ctr_used += 2;
+    const bool no_retry = env_int("HNY_NO_POOL_RETRY", 0) != 0; // tests: an overflow is an error again
+    w.pool_retry = no_retry ? nullptr : b->d_pool_retry.p;
+    w.n_pool_retry = pc;
+    w.force_pool = (u32)std::max(0, env_int("HNY_POOL_FORCE_RETRY", 0));
+    hipError_t e = launch_walk_fast(w, st);
+    if (e != hipSuccess || no_retry) return e;
+    WalkArgs h = w;
+    h.queue = pc + 1;
+    h.xcd_tile = 0;
+    h.heap_c = b->d_heap_c.p;
+    h.heap_r = b->d_heap_r.p;
+    h.heap_c_cap = b->heap_c_cap;
+    h.heap_r_cap = b->heap_r_cap;
+    return hnyk_walk_heap(b->g, h, b->shape, (int)std::min<uint32_t>(w.hi - w.lo, b->heap_grid), st);
   };
 
   const uint32_t cnt = hi - lo;

@@ -130,6 +130,14 @@ struct WalkArgs {
   const u32 *cancel; // reader mode: pinned host word, non-zero = take no further query (reader.rs:333)
   u64 *res_global;   // general kernels: result sets of more than 4 096 entries live in HBM, [grid][rcap] (else null: LDS)
   u32 xcd_tile;      // != 0: `queue` is 8 counters, one per XCD; tile k of xcd_tile members belongs to XCD k % 8
+  // Tie-pool overflow (build walks): k_walk / k_walk_sub list the member here instead of failing the build;
+  // k_walk_heap then redoes exactly those members with walk_layer's own data structures — `candidates` and
+  // `res` as real heaps in HBM (heap_c / heap_r, [grid][cap] each), no pool, nothing to overflow but memory.
+  u32 *pool_retry;   // members whose walk overflowed the 128-slot tie pool (null: count it as an error)
+  u32 *n_pool_retry;
+  u64 *heap_c, *heap_r;
+  u32 heap_c_cap, heap_r_cap;
+  u32 force_pool;    // test hook (HNY_POOL_FORCE_RETRY=n): treat every member with m % n == 0 as overflowed
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -215,6 +223,8 @@ struct LaunchShape {
 
 // kernels' host launchers (hny_kernels.hip)
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
+// the members of a.pool_retry[0 .. *a.n_pool_retry) again, on heaps in HBM (a.queue: its own work counter)
+hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
 // four queries per wave (rows <= 512 B, M0 <= 32, ef <= 127, <= 32 entry points, plain fresh build);
 // rc = 16-entry chunks of the register beam the launch needs (0: not eligible)
 int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s);

@@ -1455,6 +1455,16 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       }
       WSYNC();
     }
+    // the tie pool overflowed somewhere in this member's walks: what was computed is not the reference's
+    // result.  Build walks hand the member to k_walk_heap (same launch arguments, heaps in HBM); without a
+    // retry list (searches) the overflow is counted and fails the call.
+    if constexpr (!RM) {
+      if (a.force_pool && m % a.force_pool == 0u) s.pool_over = 1u;
+      if (s.pool_over && a.pool_retry) {
+        if (ln == 0) a.pool_retry[atomicAdd(a.n_pool_retry, 1u)] = m;
+        s.pool_over = 0;
+      }
+    }
     if (a.descend_only) { // (a batch whose level equals max_level has no greedy layer: eps stay)
       if (ln == 0) {
         a.eps_out[m] = eps[0];
@@ -1901,6 +1911,212 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
     if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
     if (s.err || res_err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
     if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// walk_layer with the reference's own data structures (hnsw.rs:460-518): `candidates` a real min-heap
+// (64-ary, HBM, keyed dist bits << 32 | ~slot: smallest distance first, larger id first among equals —
+// BinaryHeap<(Reverse<OrderedFloat>, ItemId)>), `res` a real max-heap (the same 64-ary heap on inverted
+// keys ~(dist bits << 32 | slot): MinMaxHeap::peek_max / push_pop_max), every accepted point pushed to
+// both, in list order, as the reference's loop does.  No beam array, no expanded bits, no tie pool: nothing
+// can overflow but the heaps' memory.  Slow (every heap step is a trip to HBM) and only used for the
+// members whose fast walk overflowed its 128-slot tie pool (k_walk_heap below) — inputs with a handful of
+// distinct distances and lists of hundreds of links.  Returns 0, or 1 when a heap is full.
+// rmin: the smallest key res holds (peek_min for the greedy descent; only the max ever leaves res).
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__device__ int walk_layer_heap(const GraphDev &g, const float4 (&q)[NCH], float qn, u32 layer, int ef, const u32 *eps,
+                               int n_eps, QHeap &C, QHeap &R, u64 &rmin, Visited &vis, u32 *nb_ids, float *nb_d,
+                               u64 &evals, const unsigned char *qrow) {
+  const int ln = threadIdx.x;
+  C.size = 0;
+  C.top = ~0ull;
+  R.size = 0;
+  R.top = ~0ull;
+  rmin = ~0ull;
+  for (int e0 = 0; e0 < n_eps; e0 += 64) { // :474-481 every entry point, no capacity check
+    const int ne = n_eps - e0 < 64 ? n_eps - e0 : 64;
+    u32 id = ln < ne ? eps[e0 + ln] : 0u;
+    bool isnew = visited_insert(vis, id, ln < ne);
+    u64 nmask = __ballot(isnew);
+    visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+    WSYNC();
+    if (ln < ne) nb_ids[ln] = id;
+    WSYNC();
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
+    evals += (u64)ne;
+    WSYNC();
+    for (int r = 0; r < ne; r++) {
+      const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
+      const u64 key = ((u64)db << 32) | (u64)idr;
+      if (!qheap_push(C, ((u64)db << 32) | (u64)(~idr))) return 1;
+      if (!qheap_push(R, ~key)) return 1;
+      rmin = key < rmin ? key : rmin;
+    }
+  }
+  for (;;) {
+    if (C.size == 0) break; // :483 candidates.peek()
+    const u64 top = C.top;
+    const u32 dmax = (u32)((~R.top) >> 32); // res.peek_max(), captured once per pop (:484)
+    const float fmax = __uint_as_float(dmax);
+    if (__uint_as_float((u32)(top >> 32)) > fmax) break; // raw f32 compare, :485
+    qheap_pop(C);
+    const u32 cslot = ~(u32)(top & 0xFFFFFFFFull);
+    for (int pass = g.incremental ? 0 : 1; pass < 2; pass++) { // on-disk Links first (:438-441)
+      u32 cap;
+      const u32 *nl = pass == 0 ? disk_ids(g, layer, cslot, cap) : nbr_ids(g, layer, cslot, cap);
+      if (!nl) continue;
+      for (u32 c0 = 0; c0 < cap; c0 += 64u) { // lists of more than 64 slots: 64 at a time, in list order
+        const u32 pcap = cap - c0 < 64u ? cap - c0 : 64u;
+        u32 id = (u32)ln < pcap ? nl[c0 + ln] : HNY_SENT;
+        const bool valid = id != HNY_SENT;
+        bool isnew = visited_insert(vis, id, valid); // :493
+        u64 nmask = __ballot(isnew);
+        if (!nmask) continue;
+        visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+        // the same id twice in one list (add_link never dedups, :521): the FIRST occurrence is the one the
+        // reference scores; which of the two lanes the atomic told "new" is arbitrary
+        WSYNC();
+        nb_ids[ln] = valid ? id : HNY_SENT;
+        WSYNC();
+        int firstj = ln;
+        bool anynew = isnew;
+        for (int j = 0; j < (int)pcap; j++) {
+          const u32 oj = nb_ids[j];
+          if (valid && oj == id) {
+            if (j < firstj) firstj = j;
+            if ((nmask >> j) & 1ull) anynew = true;
+          }
+        }
+        isnew = valid && anynew && firstj == ln;
+        if (g.incremental) isnew = isnew && g.has_vec[id] != 0; // MissingKey: visited, never scored (:498-502)
+        WSYNC();
+        nmask = __ballot(isnew);
+        if (!nmask) continue;
+        const int n_new = __popcll(nmask);
+        const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
+        if (isnew) nb_ids[rank] = id;
+        WSYNC();
+        dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow); // :503
+        evals += (u64)n_new;
+        WSYNC();
+        for (int r = 0; r < n_new; r++) { // list order, one at a time like the reference's loop
+          const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
+          if ((int)R.size < ef || __uint_as_float(db) < fmax) { // :505
+            const u64 key = ((u64)db << 32) | (u64)idr;
+            if (!qheap_push(C, ((u64)db << 32) | (u64)(~idr))) return 1;
+            if ((int)R.size == ef) { // push_pop_max: the new key, unless it is the greatest itself
+              if (key < ~R.top) {
+                qheap_pop(R);
+                if (!qheap_push(R, ~key)) return 1;
+                rmin = key < rmin ? key : rmin;
+              }
+            } else {
+              if (!qheap_push(R, ~key)) return 1;
+              rmin = key < rmin ? key : rmin;
+            }
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+// k_walk's member loop for the members of a.pool_retry (build walks only), every walk_layer call on heaps
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u32 *nb_ids = reinterpret_cast<u32 *>(smem);
+  float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
+  u32 *eps = reinterpret_cast<u32 *>(nb_d + 64);
+  const int ln = threadIdx.x, t = ln % LPR;
+  const u32 n_mem = *a.n_pool_retry;
+  if (n_mem == 0u) return;
+  Visited vis;
+  visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words, a.vlog + (size_t)blockIdx.x * a.log_cap,
+               a.log_cap, nullptr, 0u);
+  QHeap C, R;
+  C.h = a.heap_c + (size_t)blockIdx.x * a.heap_c_cap;
+  C.cap = a.heap_c_cap;
+  R.h = a.heap_r + (size_t)blockIdx.x * a.heap_r_cap;
+  R.cap = a.heap_r_cap;
+  u64 evals = 0;
+  u32 err = 0, log_over_cnt = 0;
+  for (;;) {
+    u32 mi = 0;
+    if (ln == 0) mi = atomicAdd(a.queue, 1u);
+    mi = uni(mi);
+    if (mi >= n_mem) break;
+    const u32 m = uni(a.pool_retry[mi]);
+    const u32 qslot = a.q_slots[m];
+    const unsigned char *qrow = g.rows + (size_t)qslot * g.row_stride;
+    const float qn = g.norms ? g.norms[qslot] : 0.f;
+    float4 q[NCH];
+    load_row<LPR, NCH>(qrow, t, g.n16, q);
+    int n_eps;
+    u32 start_layer;
+    if (a.first) { // hnsw.rs:298 eps = all entry points
+      n_eps = (int)a.n_entry_points;
+      for (int i = ln; i < n_eps; i += 64) eps[i] = a.entry_points[i];
+      start_layer = g.max_level;
+    } else if (a.eps_in) { // resume after a descend_only launch
+      n_eps = 1;
+      if (ln == 0) eps[0] = a.eps_in[m];
+      start_layer = a.layer;
+    } else { // :316-321 eps = what was selected on the layer above
+      const u64 *sl = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - (a.layer + 1)) * (a.cap_sel + 1);
+      n_eps = (int)sl[0];
+      if (ln < n_eps) eps[ln] = (u32)(sl[1 + ln] & 0xFFFFFFFFull);
+      start_layer = a.layer;
+    }
+    WSYNC();
+    u64 lkey = 0, rmin = ~0ull;
+    int st = 0;
+    for (u32 layer = start_layer;; layer--) {
+      const bool last = (layer == a.layer);
+      if (last && a.descend_only) break;
+      st = walk_layer_heap<LPR, NCH>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, C, R, rmin, vis, nb_ids, nb_d,
+                                     evals, qrow);
+      if (st || last) break;
+      const u32 closest = (u32)(rmin & 0xFFFFFFFFull); // :305-306 eps = [peek_min]
+      WSYNC();
+      if (ln == 0) eps[0] = closest;
+      n_eps = 1;
+      lkey = (lkey << 16) | (u64)((u32)g.upper_idx[closest] & 0xFFFFu);
+      if (vis.log_over) log_over_cnt++;
+      visited_clear(vis); // walk_layer owns a fresh visited set
+      WSYNC();
+    }
+    if (!st && a.descend_only) {
+      if (ln == 0) {
+        a.eps_out[m] = eps[0];
+        a.key_out[m - a.key_base] = lkey & 0xFFFFFFFFFFFFull;
+      }
+    } else if (!st) {
+      // res.into_vec(), ascending: pop the maxima into the row from its end
+      const u32 total = R.size;
+      if (total > a.rcap) {
+        st = 1;
+      } else {
+        for (u32 i = total; i-- > 0u;) {
+          const u64 key = ~R.top;
+          if (ln == 0) a.cand[(size_t)m * a.rcap + i] = key;
+          qheap_pop(R);
+        }
+        if (ln == 0) a.cand_n[m] = total;
+      }
+    }
+    if (st) err = 1;
+    if (vis.log_over) log_over_cnt++;
+    visited_clear(vis);
+    WSYNC();
+  }
+  if (ln == 0) {
+    if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
+    if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
+    if (err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
   }
 }
 
@@ -3276,6 +3492,14 @@ struct NnsFilteredLauncher {
   }
 };
 template <int L, int C>
+struct WalkHeapLauncher {
+  static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
+    const size_t lds = 64 * 4 * 2 + (size_t)a.eps_cap * 4;
+    hipLaunchKernelGGL((k_walk_heap<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
 struct NnsLinearLauncher {
   static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
     size_t lds = (size_t)a.rcap * 8 + 64 * 4 * 2;
@@ -3407,6 +3631,9 @@ int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s) {
 size_t hnyk_walk_sub_lds(int rc) { return walk_sub_lds_bytes(rc); }
 hipError_t hnyk_walk_sub(const GraphDev &g, const WalkArgs &a, LaunchShape s, int rc, int grid, hipStream_t st) {
   HNY_SP_SWITCH(hnyk_walk_sub_sp, g, a, s.lpr, rc, grid, st)
+}
+hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<WalkHeapLauncher>(s, g, a, grid, st);
 }
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<NnsFilteredLauncher>(s, g, a, grid, st);

@@ -124,10 +124,12 @@ def test_fuzz_invariants(H, M0):
         assert np.all(dists[got[:, 0] == np.array(ids, np.uint32), 0] < 1e-6)
 
 
-def test_all_items_are_reachable(H):
-    """src/tests/reader.rs:82-98: M = M0 = 6, nns(n).ef_search(n) from the zero vector finds all"""
+@pytest.mark.parametrize("n,dim", [(500, 64), (9999, 768)])
+def test_all_items_are_reachable(H, n, dim):
+    """src/tests/reader.rs:82-98: M = M0 = 6, nns(n).ef_search(n) from the zero vector finds all — at the
+    reference's own largest case (proptest n in 1..10000, DIM 768): a result set of 9 999 entries lives in
+    HBM (general walk kernel), every distance ties at 0.0"""
     rng = np.random.default_rng(7)
-    n, dim = 500, 64
     db = H.Database(None, H.Metric.COSINE)
     w = db.writer(dim, m=6, ef=100)
     w.add_items(range(n), rng.uniform(-1, 1, (n, dim)).astype(np.float32))

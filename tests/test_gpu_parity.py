@@ -1086,22 +1086,24 @@ def test_resident_multi_builder_runs_twice(orc, hny, monkeypatch):
 
 
 def test_native_multi_gpu_overflow_in_a_shard_fails_the_build(orc, hny, monkeypatch):
-    """A device-side overflow inside the shard of a rank >= 1 exists only in THAT rank's counter block
-    (rank 0 never walked those members), while its clipped selection is all-gathered into every replica:
-    every rank's error words are folded into the ranks' agreement, so the build fails exactly as it does
-    on one GPU — with HNY_MGPU_VERIFY off, i.e. without the replica comparison that used to mask this."""
+    """A device-side error inside the shard of a rank >= 1 exists only in THAT rank's counter block (rank 0
+    never walked those members), while the clipped selection is all-gathered into every replica: every
+    rank's error words are folded into the ranks' agreement, so the build fails exactly as it does on one
+    GPU — with HNY_MGPU_VERIFY off, i.e. without the replica comparison that used to mask this.  The error
+    here: a tie-pool overflow with the heap-walk safety net switched off (HNY_NO_POOL_RETRY=1).  With the
+    net on, the same sharded build equals the oracle."""
     monkeypatch.setenv("HNY_MGPU_SHIM", "1")
     monkeypatch.delenv("HNY_MGPU_VERIFY", raising=False)
     monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "4")
     monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
-    h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
-    metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
-    frac = float(h["frac"][0])
-    ds = orc.Dataset.from_f32(metric, h["mat0"], h["lv0"], h["ids0"])
-    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    h, ds, items, metric, dim, M, M0, ef, bmax, frac = _tie_pool_fixture(orc, hny)
+    kw = dict(M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax, threads=8)
+    _same_graph(hny.build(items, devices=[0, 0], **kw), o)
+    monkeypatch.setenv("HNY_NO_POOL_RETRY", "1")
     for world in (2, 3):
         with pytest.raises(hny.HannoyError) as e:
-            hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax, devices=[0] * world)
+            hny.build(items, devices=[0] * world, **kw)
         assert e.value.code == -7 and "tie pool overflow" in str(e.value)
 
 
@@ -1152,31 +1154,59 @@ def test_xcd_tiled_walk_queue_equals_oracle(orc, hny, monkeypatch, metric, n, di
     assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
-def test_tie_pool_overflow_fails_loudly(orc, hny):
-    """Found by scripts/soak_random_configs.py: 3-bit Hamming codes (four distinct distances) and M0 = 333 —
-    hundreds of evicted candidates tie with the result set's maximum at once, more than the walk's
-    128-slot tie pool holds.  Dropping them used to be visible in `n_tie_pool_overflow` only, and an
-    update of this index came out with 46 records different from the oracle's; now the call fails with
-    HNY_ERR_DEVICE.  With M0 = 64 the same data builds and updates exactly."""
+def _tie_pool_fixture(orc, hny):
     h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
     metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
     frac = float(h["frac"][0])
     ds = orc.Dataset.from_f32(metric, h["mat0"], h["lv0"], h["ids0"])
     items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
-    with pytest.raises(hny.HannoyError) as e:
-        hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
-    assert e.value.code == -7 and "tie pool overflow" in str(e.value)
-    kw_o = dict(M=M, M0=64, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax)
-    kw_g = dict(M=M, M0=64, ef_construction=ef, batch_frac=frac, batch_max=bmax)
+    return h, ds, items, metric, dim, M, M0, ef, bmax, frac
+
+
+def test_tie_pool_overflow_equals_oracle(orc, hny, monkeypatch):
+    """Found by scripts/soak_random_configs.py: 3-bit Hamming codes (four distinct distances) and M0 = 333 —
+    hundreds of evicted candidates tie with the result set's maximum at once, more than the walk's
+    128-slot tie pool holds.  Round 2 failed such a build (HNY_ERR_DEVICE); now the walk lists the member
+    and k_walk_heap walks it again with `candidates` and `res` as real heaps in HBM — the reference's own
+    data structures, nothing to overflow — so the build and the update equal the oracle's, edge for edge.
+    HNY_NO_POOL_RETRY=1 switches the safety net off: the same input fails loudly, as before."""
+    h, ds, items, metric, dim, M, M0, ef, bmax, frac = _tie_pool_fixture(orc, hny)
+    kw_o = dict(M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=frac, batch_max=bmax)
+    kw_g = dict(M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax)
     og = orc.build(ds, threads=8, **kw_o)
     gg = hny.build(items, **kw_g)
+    assert gg.n_tie_pool_overflow == 0
     _same_graph(gg, og)
+    assert gg.n_links_added == og.n_links_added and gg.n_evals_walk == og.n_evals_walk
     ds2 = orc.Dataset.from_f32(metric, h["mat1"], np.zeros(len(h["ids1"]), np.uint8), h["ids1"])
     items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, h["lv1"])
     og2 = orc.build_incremental(ds2, og, h["ins1"], h["lv1"], h["del1"], **kw_o)
     gg2 = hny.build_incremental(items2, gg, h["ins1"], h["del1"], **kw_g)
     _same_graph(gg2, og2)
-    assert gg2.n_tie_pool_overflow == 0
+    assert gg2.n_tie_pool_overflow == 0 and gg2.n_evals_walk == og2.n_evals_walk
+    monkeypatch.setenv("HNY_NO_POOL_RETRY", "1")
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build(items, **kw_g)
+    assert e.value.code == -7 and "tie pool overflow" in str(e.value)
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,every", [(0, 2500, 96, 8, 16, 40, 1), (3, 3000, 256, 8, 16, 32, 3),
+                                                       (1, 1500, 768, 16, 32, 64, 2), (4, 2000, 128, 6, 80, 24, 1)])
+def test_heap_walk_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, ef, every):
+    """k_walk_heap on ordinary inputs: HNY_POOL_FORCE_RETRY=k hands every k-th member of every walk launch
+    (descent launches, every layer, locality order, M0 > 64) to the heap kernel as if its tie pool had
+    overflowed — graph, link count and walk evaluations stay the oracle's."""
+    monkeypatch.setenv("HNY_POOL_FORCE_RETRY", str(every))
+    rng = np.random.default_rng(n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=9))
+    for kw in (dict(batch_frac=1.0, batch_max=4096), dict(batch_frac=0.05, batch_max=64)):
+        o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+        g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+        _same_graph(g, o)
+        assert g.n_links_added == o.n_links_added
+        # a handed-over member is walked twice: the fast kernel's (discarded) evaluations count too
+        assert g.n_evals_walk >= o.n_evals_walk
 
 
 @pytest.mark.parametrize("tile", [16, 0])
