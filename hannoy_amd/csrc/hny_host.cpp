@@ -910,6 +910,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   g.n16 = n16;
   g.row_stride = n16 * 16;
   g.bin_bits = (u32)(vb * 8);
+  g.bin_inv = (g.bin_bits && (g.bin_bits & (g.bin_bits - 1)) == 0) ? 1.0f / (float)g.bin_bits : 0.0f;
   g.M = o.M;
   g.M0 = o.M0;
   g.max_level = b->max_level;

@@ -76,6 +76,7 @@ struct GraphDev {
   const u32 *d0_ids;            // [n][M0] old layer-0 Links, ascending, HNY_SENT padded
   const u32 *du_ids;            // [n_upper][up_layers][M]
   const unsigned char *has_vec; // [n] 0 = deleted item (no Item record any more)
+  float bin_inv;                // 1 / bin_bits when bin_bits is a power of two (exact), else 0
 };
 
 struct WalkArgs {

@@ -292,8 +292,9 @@ __device__ __forceinline__ float finalize_f32(const GraphDev &g, float acc, floa
 
 __device__ __forceinline__ float finalize_bin(const GraphDev &g, u32 pop, float qn, float rn) {
   switch (g.metric) {
-    case 3: // hamming.rs:44-47: popcount / padded dims
-      return (float)pop / (float)g.bin_bits;
+    case 3: // hamming.rs:44-47: popcount / padded dims.  A power-of-two divisor (bin_inv != 0: its exact
+      // reciprocal) makes the IEEE division an exact scaling: one multiply, the same bits
+      return g.bin_inv != 0.f ? (float)pop * g.bin_inv : (float)pop / (float)g.bin_bits;
     case 4: { // binary_quantized_cosine.rs:44-59
       float pq = (float)((int)g.bin_bits - 2 * (int)pop);
       float pnqn = qn * rn;
@@ -667,6 +668,18 @@ struct Beam {
 // fl(sqrt(D))^2 < D).  Such entries sort last in every heap but never trigger the `f > f_max`
 // break, so evicted ones must stay poppable.
 __device__ __forceinline__ bool weird_bits(u32 b) { return b > 0x7F800000u; }
+
+// minimum of a 64-bit value over the wave, on every lane: xor butterfly on DPP / permlane swaps (no LDS)
+template <int OFF>
+__device__ __forceinline__ u64 wave_min_step(u64 v) {
+  if constexpr (OFF >= 1) {
+    const u64 o = xshfl<OFF>(v);
+    return wave_min_step<OFF / 2>(o < v ? o : v);
+  } else {
+    return v;
+  }
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) { return wave_min_step<32>(v); }
 
 __device__ __forceinline__ void pool_push(Beam &s, u64 key) {
   if (s.pool_len < HNY_POOL_CAP) {
@@ -1145,6 +1158,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     }
     u64 tp = ~0ull;
     int pi = -1;
+#ifdef HNY_POOL_SCAN_SHFL // round 2's scan, kept for same-box A/B builds (scripts/r3_ab_lib.sh)
     if (s.pool_len > 0) {
       for (int e = ln; e < s.pool_len; e += 64) {
         u64 k = s.pool[e];
@@ -1166,6 +1180,24 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       tp = uni(tp);
       pi = uni(pi);
     }
+#else
+    if (s.pool_len > 0) {
+      // the pool's minimum in pop order (distance bits ascending, then id DESCENDING): two entries per lane
+      // at most, one DPP butterfly, the owner found by ballot (keys are unique: one slot, one key).  (The
+      // entry-by-entry scan with a shuffle argmin that stood here was 250 of the 1 350 instructions of a
+      // C5 expansion: Hamming distances tie all the time, the pool is non-empty in 2 of 3 expansions.)
+      static_assert(HNY_POOL_CAP == 128, "two pool entries per lane");
+      const bool h0 = ln < s.pool_len, h1 = ln + 64 < s.pool_len;
+      const u64 k0 = h0 ? s.pool[ln] : 0ull, k1 = h1 ? s.pool[ln + 64] : 0ull;
+      const u64 t0 = h0 ? ((k0 & 0xFFFFFFFF00000000ull) | (u64)(~(u32)(k0 & 0xFFFFFFFFull))) : ~0ull;
+      const u64 t1 = h1 ? ((k1 & 0xFFFFFFFF00000000ull) | (u64)(~(u32)(k1 & 0xFFFFFFFFull))) : ~0ull;
+      const bool second = h1 && t1 < t0;
+      const u64 mine = second ? t1 : t0;
+      tp = uni(wave_min_u64(mine));
+      const int wl = __ffsll((long long)__ballot(h0 && mine == tp)) - 1; // h0: the lane holds an entry at all
+      pi = wl + (((__ballot(second) >> wl) & 1ull) ? 64 : 0);
+    }
+#endif
     const bool have_a = first_un >= 0, have_p = pi >= 0;
     if (!have_a && !have_p) break; // candidates exhausted (or only dropped entries: they break)
     const bool use_pool = have_p && (!have_a || tp < ta);
@@ -1391,6 +1423,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     m = uni(m);
     if (m >= a.hi) break;
     if (a.perm) m = uni((u32)a.perm[m - a.lo]); // locality order; results stay indexed by member
+    const u64 evals_before = evals;
     const unsigned char *qrow;
     float qn = 0.f;
     if (a.q_rows) {
@@ -1463,6 +1496,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       if (s.pool_over && a.pool_retry) {
         if (ln == 0) a.pool_retry[atomicAdd(a.n_pool_retry, 1u)] = m;
         s.pool_over = 0;
+        evals = evals_before; // the heap kernel counts this member's evaluations (the reference's number)
       }
     }
     if (a.descend_only) { // (a batch whose level equals max_level has no greedy layer: eps stay)
@@ -1584,17 +1618,6 @@ struct QHeap {
   u32 size, cap;
   u64 top;
 };
-
-template <int OFF>
-__device__ __forceinline__ u64 wave_min_step(u64 v) {
-  if constexpr (OFF >= 1) {
-    const u64 o = xshfl<OFF>(v);
-    return wave_min_step<OFF / 2>(o < v ? o : v);
-  } else {
-    return v;
-  }
-}
-__device__ __forceinline__ u64 wave_min_u64(u64 v) { return wave_min_step<32>(v); }
 
 __device__ __forceinline__ bool qheap_push(QHeap &Q, u64 key) {
   if (Q.size >= Q.cap) return false;

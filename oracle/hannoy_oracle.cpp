@@ -446,6 +446,11 @@ struct Scratch {
   uint64_t evals = 0;
   uint64_t evals_walk = 0; /* the hnsw.rs:476,503 call sites alone (schedule-determined) */
   std::vector<uint32_t> nbuf;
+  /* diagnostics (ORC_TRACE_EVALS=path, scripts/r3_row_overlap.py): which rows every level-0 ef-walk of the
+   * batch-synchronous schedule scores — records [0xFFFFFFFF, query slot, first entry point, slots...] */
+  std::vector<uint32_t> trace;
+  bool tracing = false;
+  uint32_t trace_q = 0;
   void begin(uint32_t n) {
     if (stamp.size() != n) {
       stamp.assign(n, 0);
@@ -487,9 +492,16 @@ void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint3
                                 [](const Link &a, uint64_t key) { return link_key(a) < key; });
     res.insert(pos, l);
   };
+  const bool tr = S.tracing && layer == 0 && ef > 1;
+  if (tr) {
+    S.trace.push_back(0xFFFFFFFFu);
+    S.trace.push_back(S.trace_q);
+    S.trace.push_back(eps.empty() ? 0u : eps[0]);
+  }
   for (uint32_t ep : eps) { /* :474-481 — no capacity check on res here */
     Link l{qd(ep, S.evals), ep};
     S.evals_walk++;
+    if (tr) S.trace.push_back(ep);
     cand.push(l);
     res_insert(l);
     S.visit(ep);
@@ -516,6 +528,7 @@ void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint3
       if (B.incremental && !B.has_vec[p]) continue; /* MissingKey => deleted item, :498-502 */
       float d = qd(p, S.evals);  /* :503 */
       S.evals_walk++;
+      if (tr) S.trace.push_back(p);
       if (res.size() < ef || d < f_max) { /* :505, f_max captured once per pop */
         Link l{d, p};
         cand.push(l);
@@ -581,6 +594,7 @@ struct Selection {
 
 /* hnsw.rs:291-328 insert, split into its read-only half (search + prune) ... */
 void insert_search(Builder &B, Scratch &S, uint32_t q, uint32_t level, Selection &out) {
+  S.trace_q = q;
   std::vector<uint32_t> eps(B.entry_points.begin(), B.entry_points.end()); /* :298 */
   auto qd = [&](uint32_t p, uint64_t &ctr) { return B.d_items(q, p, ctr); };
   std::vector<Link> res;
@@ -804,6 +818,9 @@ static void run_schedule(Builder &B, const orc_opts *opts,
       size_t bend = std::min(gend, pos + bsz);
       size_t cnt = bend - pos;
       std::vector<Selection> sels(cnt);
+      const char *trace_path = std::getenv("ORC_TRACE_EVALS"); /* diagnostics: the LAST batch's level-0 walks */
+      const bool trace_now = trace_path && bend == ord.size();
+      for (auto &sc : scratch) sc.tracing = trace_now;
       if (nthreads == 1) {
         for (size_t i = 0; i < cnt; i++)
           insert_search(B, scratch[0], ord[pos + i].first, ord[pos + i].second, sels[i]);
@@ -819,6 +836,16 @@ static void run_schedule(Builder &B, const orc_opts *opts,
             }
           });
         for (auto &t : th) t.join();
+      }
+      if (trace_now) {
+        if (FILE *f = std::fopen(trace_path, "wb")) {
+          for (auto &sc : scratch) {
+            if (!sc.trace.empty()) std::fwrite(sc.trace.data(), 4, sc.trace.size(), f);
+            sc.trace.clear();
+            sc.tracing = false;
+          }
+          std::fclose(f);
+        }
       }
       bool was_threaded = B.threaded;
       B.threaded = false; /* apply is sequential by definition */

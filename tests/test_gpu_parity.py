@@ -1205,8 +1205,7 @@ def test_heap_walk_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, e
         g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
         _same_graph(g, o)
         assert g.n_links_added == o.n_links_added
-        # a handed-over member is walked twice: the fast kernel's (discarded) evaluations count too
-        assert g.n_evals_walk >= o.n_evals_walk
+        assert g.n_evals_walk == o.n_evals_walk  # the discarded first walk of a handed-over member is not counted
 
 
 @pytest.mark.parametrize("tile", [16, 0])
