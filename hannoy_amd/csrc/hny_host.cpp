@@ -1242,8 +1242,26 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   b->pool_ctr_used = 0;
   // one walk launch: rows <= 512 B go to the four-queries-per-wave kernel first, and the one-wave
   // kernel then takes the members it gave up on (none, normally) from the retry list
+  // HNY_GRP=0 keeps every level-0 walk on k_walk; HNY_GRP_CACHE = entries of a member's distance cache
+  const bool grp_on = env_int("HNY_GRP", 1) != 0;
   auto launch_walk_fast = [&](WalkArgs w, hipStream_t st) -> hipError_t {
     const uint32_t n = w.hi - w.lo;
+    if (grp_on && n >= 8192u && hnyk_walk_grp_ok(b->g, w, b->shape)) {
+      // four neighbouring members per workgroup with distance sharing (k_walk_grp).  LDS: three workgroups per
+      // CU (12 waves); what the distance caches leave goes to the waves' visited tables, in whole 64-entry rows
+      WalkArgs gw = w;
+      u32 cache = 64;
+      const u32 want = (u32)std::max(64, std::min(1024, env_int("HNY_GRP_CACHE", 512)));
+      while (cache * 2 <= want) cache *= 2;
+      gw.grp_cache = cache;
+      const size_t budget = (size_t)160 * 1024 / 3 - 64;
+      const size_t fixed = 4 * (hnyk_walk_grp_lds_bytes(w.rcap, 0, 0) - 64) / 4 + (size_t)4 * cache * 8;
+      gw.vis_slots = budget > fixed ? (u32)((budget - fixed) / 16 / 64 * 64) : 0u;
+      if (gw.vis_slots >= 512u) {
+        const uint32_t groups = (n + 3) / 4;
+        return hnyk_walk_grp(b->g, gw, b->shape, (int)std::min<uint32_t>(groups, std::min<uint32_t>(b->walk_slots / 4, 768u)), st);
+      }
+    }
     const int rc = b->sub_blocks && b->ctr_used + 3 <= b->d_ctr.n ? hnyk_walk_sub_rc(b->g, w, b->shape) : 0;
     if (!rc) return hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
     u32 *ctr = b->d_ctr.p + b->ctr_used;
@@ -1726,6 +1744,9 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
           stats[ST_PH_POP], stats[ST_PH_LIST], stats[ST_PH_DIST], stats[ST_PH_INSERT], stats[ST_PH_EXPANSIONS],
           stats[ST_PH_REST]);
 #endif
+  if (getenv("HNY_DEBUG_GRP"))
+    fprintf(stderr, "[hny] grouped walk: %llu distances taken from the caches, %llu scored for partners, %llu walk evaluations\n",
+            stats[ST_GRP_HITS], stats[ST_GRP_DEPOSITS], stats[ST_EVALS_WALK]);
   if (getenv("HNY_DEBUG_COUNTS"))
     fprintf(stderr, "[hny] expansions %llu accepted %llu notfull %llu evals_walk %llu\n", stats[9], stats[10], stats[11],
             stats[ST_EVALS_WALK]);

@@ -38,11 +38,13 @@ enum {
   ST_SUB_RETRY = 13, // walks k_walk_sub handed over to k_walk
   ST_SUB_RETRY_VIS = 14,  // ... because the visited table filled up
   ST_SUB_RETRY_POOL = 15, // ... because the tie pool filled up
+  ST_GRP_HITS = 16,       // k_walk_grp: distances a member found in its cache (rows it did not load)
+  ST_GRP_DEPOSITS = 17,   // ... distances scored for partners
 #ifdef HNY_PHASE_CLOCKS // diagnostic build (HNY_CFLAGS=-DHNY_PHASE_CLOCKS): wave cycles per walk phase
-  ST_PH_POP = 16, ST_PH_LIST = 17, ST_PH_DIST = 18, ST_PH_INSERT = 19, ST_PH_EXPANSIONS = 20, ST_PH_REST = 21,
+  ST_PH_POP = 18, ST_PH_LIST = 19, ST_PH_DIST = 20, ST_PH_INSERT = 21, ST_PH_EXPANSIONS = 22, ST_PH_REST = 23,
   ST_COUNT = 24
 #else
-  ST_COUNT = 16
+  ST_COUNT = 18
 #endif
 };
 
@@ -139,6 +141,7 @@ struct WalkArgs {
   u64 *heap_c, *heap_r;
   u32 heap_c_cap, heap_r_cap;
   u32 force_pool;    // test hook (HNY_POOL_FORCE_RETRY=n): treat every member with m % n == 0 as overflowed
+  u32 grp_cache;     // k_walk_grp: entries of a member's distance cache (a power of two)
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -226,6 +229,10 @@ struct LaunchShape {
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
 // the members of a.pool_retry[0 .. *a.n_pool_retry) again, on heaps in HBM (a.queue: its own work counter)
 hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
+// four members per workgroup with distance sharing (k_walk_grp); grid = workgroups of 4 waves
+bool hnyk_walk_grp_ok(const GraphDev &g, const WalkArgs &a, LaunchShape s);
+size_t hnyk_walk_grp_lds_bytes(u32 rcap, u32 vis_slots, u32 cache);
+hipError_t hnyk_walk_grp(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
 // four queries per wave (rows <= 512 B, M0 <= 32, ef <= 127, <= 32 entry points, plain fresh build);
 // rc = 16-entry chunks of the register beam the launch needs (0: not eligible)
 int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s);
@@ -270,6 +277,7 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
   hipError_t hnyk_walk_sp##N(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st); \
   hipError_t hnyk_walk_sub_sp##N(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid,          \
                                  hipStream_t st);                                                           \
+  hipError_t hnyk_walk_grp_sp##N(const GraphDev &g, const WalkArgs &a, int nch, int grid, hipStream_t st);  \
   hipError_t hnyk_prune_wg_sp##N(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw,      \
                                  int grid, hipStream_t st);                                                 \
   hipError_t hnyk_apply_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,               \

@@ -1154,6 +1154,33 @@ def test_xcd_tiled_walk_queue_equals_oracle(orc, hny, monkeypatch, metric, n, di
     assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
+@pytest.mark.parametrize("metric,n,dim,ef,cache,every", [(0, 20000, 520, 40, 512, 0), (1, 18000, 700, 150, 64, 0),
+                                                         (2, 17000, 300, 32, 1024, 0), (0, 17000, 768, 24, 256, 5)])
+def test_grouped_walk_equals_oracle(orc, hny, monkeypatch, metric, n, dim, ef, cache, every):
+    """k_walk_grp: the level-0 walks of a batch of >= 8 192 members on 2 / 3 KB f32 rows run four neighbouring
+    members per workgroup, every loaded row scored for all four and the partners' distances left in their
+    LDS caches.  Whoever computes a distance computes it in the wave order, so graph, link count and walk
+    evaluations stay the oracle's — for register beams (ef <= 127) and LDS beams (ef = 150), tiny (64-entry)
+    and large caches, short last groups (n not a multiple of 4), and with members handed to k_walk_heap
+    (HNY_POOL_FORCE_RETRY); HNY_GRP=0 (one wave per member, no sharing) builds the same graph."""
+    monkeypatch.setenv("HNY_GRP_CACHE", str(cache))
+    if every:
+        monkeypatch.setenv("HNY_POOL_FORCE_RETRY", str(every))
+    rng = np.random.default_rng(n + dim)
+    cent = rng.uniform(-1, 1, (24, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 24, n)] + 0.2 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, 8, seed=5))
+    kw = dict(batch_frac=1.0, batch_max=8193)
+    o = orc.build(ds, M=8, M0=16, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    g = hny.build(items, M=8, M0=16, ef_construction=ef, **kw)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+    monkeypatch.setenv("HNY_GRP", "0")
+    g0 = hny.build(items, M=8, M0=16, ef_construction=ef, **kw)
+    _same_graph(g0, o)
+    assert g0.n_evals_walk == o.n_evals_walk
+
+
 def _tie_pool_fixture(orc, hny):
     h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
     metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
