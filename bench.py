@@ -376,8 +376,7 @@ def main():
                 "t_prune_kernels_s": round(g.t_prune_kernels_s, 3),
                 "t_sort_kernels_s": round(g.t_sort_kernels_s, 3),
                 "t_apply_kernels_s": round(g.t_apply_kernels_s, 3),
-                "tie_pool_overflow": int(g.n_tie_pool_overflow),
-                "sub_wave_walks": int(g.n_sub_walks), "sub_wave_handed_over": int(g.n_sub_retries)}
+                "tie_pool_overflow": int(g.n_tie_pool_overflow)}
 
     builder, driver, graph, dt = timed_builds(items, a.steps, a.warmup)
     value = a.n * a.steps / dt if a.steps else 0.0

@@ -97,8 +97,7 @@ class GraphStruct(C.Structure):
                 ("n_tie_pool_overflow", C.c_uint64),
                 ("t_walk_kernels_s", C.c_double), ("t_prune_kernels_s", C.c_double),
                 ("t_sort_kernels_s", C.c_double), ("t_apply_kernels_s", C.c_double),
-                ("n_walk_launches", C.c_uint64), ("n_sub_walks", C.c_uint64),
-                ("n_sub_retries", C.c_uint64)]
+                ("n_walk_launches", C.c_uint64)]
 
 
 class PrevGraph(C.Structure):
@@ -421,8 +420,7 @@ class Graph:
         for f in ("n_links_added", "n_distance_evals", "n_evals_walk", "n_evals_prune",
                   "n_evals_apply", "n_batches", "t_upload_s", "t_build_s", "t_export_s",
                   "n_tie_pool_overflow", "t_walk_kernels_s", "t_prune_kernels_s",
-                  "t_sort_kernels_s", "t_apply_kernels_s", "n_walk_launches", "n_sub_walks",
-                  "n_sub_retries"):
+                  "t_sort_kernels_s", "t_apply_kernels_s", "n_walk_launches"):
             setattr(self, f, getattr(g, f))
         self._gp, self._opts, self._items = gp, opts, items
 

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhannoy_amd.so")
 SOURCES = ["hny_host.cpp", "hny_multi.cpp", "hny_kernels.hip", "hny_lmdb.cpp"]
 HOST_ONLY = {"hny_lmdb.cpp"}  # no device code: compiled as plain C++
-HEADERS = [os.path.join(CSRC, "hny_internal.h"), os.path.join(CSRC, "hny_walk_sub.h"),
+HEADERS = [os.path.join(CSRC, "hny_internal.h"),
            os.path.join(CSRC, "hny_rust_sort.h"),
            os.path.join(os.path.dirname(HERE), "include", "hannoy_amd.h")]
 # -ffp-contract=off: FMAs only where the source says fmaf (parity with the oracle's orders);

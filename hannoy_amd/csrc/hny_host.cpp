@@ -279,16 +279,11 @@ struct hny_builder {
   DevBuf<u64> d_gap_keys, d_gap_sorted;
   int gap_grid = 0;
   DevBuf<u32> d_eps0;
-  // k_walk_sub (four queries per wave): per-query visited hash tables, the retry list and the work /
-  // retry counters of a search call (3 words per walk launch)
-  DevBuf<u32> d_vtab, d_ctr;
-  DevBuf<u64> d_retry;
   // k_walk_heap (walk_layer on heaps in HBM) for the members whose walk overflowed its tie pool: the list
   // of those members, a (count, work counter) pair per walk launch of a search call, the heaps
   DevBuf<u32> d_pool_retry, d_pool_ctr;
   DevBuf<u64> d_heap_c, d_heap_r;
   uint32_t heap_grid = 0, heap_c_cap = 0, heap_r_cap = 0, pool_ctr_used = 0;
-  uint32_t sub_blocks = 0, vtab_slots = 0, ctr_used = 0;
   bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
   DevBuf<u64> d_stats, d_stats_scratch, d_sel, d_cand, d_res_global, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
@@ -972,36 +967,6 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_perm_b.alloc(cand_rows));
   HIP_TRY(b->d_eps0.alloc(cand_rows));
   {
-    // sub-wave walk: one visited hash table per resident QUERY (4 per wave).  A walk marks about
-    // 0.4 ... 0.6 x ef x M0 items (measured: C5 1 245, C4 1 390); the table wants a load factor
-    // around 1/3 (16-id buckets then almost never fill) and must stay cache resident: 16 KB x
-    // 4 x blocks.  A walk that fills 3/4 of it goes to the one-wave kernel instead.
-    WalkArgs probe{};
-    probe.ef = o.ef_construction;
-    probe.n_entry_points = (u32)b->entry_points.size();
-    probe.cap_sel = o.M0;
-    GraphDev gp{};
-    gp.metric = o.metric;
-    gp.M = o.M;
-    gp.M0 = o.M0;
-    gp.incremental = inc ? 1 : 0;
-    gp.x86_order = o.x86_order ? 1 : 0;
-    if (hnyk_walk_sub_rc(gp, probe, b->shape)) { // HNY_SUB=1 at builder creation
-      uint32_t vs = 512;
-      const uint32_t want = (uint32_t)std::min<int64_t>(
-          std::max(512, env_int("HNY_SUB_VSLOTS", (int)std::min<uint32_t>(4096, o.ef_construction * o.M0 * 3 / 2))),
-          1 << 16);
-      while (vs < want) vs *= 2;
-      b->vtab_slots = vs;
-      b->sub_blocks = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_SUB_BLOCKS", 4096)),
-                                                  (std::max<uint32_t>(b->max_batch, 256) + 3) / 4);
-      HIP_TRY(b->d_vtab.alloc((size_t)b->sub_blocks * 4 * vs));
-      HIP_TRY(hnyk_fill_u32(b->d_vtab.p, HNY_SENT, b->d_vtab.n, st));
-      HIP_TRY(b->d_retry.alloc(cand_rows));
-    }
-    HIP_TRY(b->d_ctr.alloc(3 * 32));
-  }
-  {
     // walk_layer on heaps (k_walk_heap): `candidates` never holds more than the items visited, `res` no more
     // than a candidate row; as many blocks as ~1 GB of heaps allow
     b->heap_c_cap = (uint32_t)std::min<uint64_t>((uint64_t)n + 1 + eps_cap_of(b.get()), (uint64_t)1 << 22);
@@ -1236,54 +1201,12 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   u32 *queues = b->d_nseg.p + 4; // 16 work counters: the descent + one per layer of the batch
   u32 *xqueues = queues + 16;    // the same 16, as 8 per-XCD counters each (WalkArgs.xcd_tile)
   HIP_TRY(hipMemsetAsync(queues, 0, (16 + 8 * 16) * 4, b->stream));
-  HIP_TRY(hipMemsetAsync(b->d_ctr.p, 0, b->d_ctr.n * 4, b->stream));
-  b->ctr_used = 0;
   HIP_TRY(hipMemsetAsync(b->d_pool_ctr.p, 0, b->d_pool_ctr.n * 4, b->stream));
   b->pool_ctr_used = 0;
   // one walk launch: rows <= 512 B go to the four-queries-per-wave kernel first, and the one-wave
   // kernel then takes the members it gave up on (none, normally) from the retry list
-  // HNY_GRP=0 keeps every level-0 walk on k_walk; HNY_GRP_CACHE = entries of a member's distance cache
-  const bool grp_on = env_int("HNY_GRP", 1) != 0;
-  auto launch_walk_fast = [&](WalkArgs w, hipStream_t st) -> hipError_t {
-    const uint32_t n = w.hi - w.lo;
-    if (grp_on && n >= 8192u && hnyk_walk_grp_ok(b->g, w, b->shape)) {
-      // four neighbouring members per workgroup with distance sharing (k_walk_grp).  LDS: three workgroups per
-      // CU (12 waves); what the distance caches leave goes to the waves' visited tables, in whole 64-entry rows
-      WalkArgs gw = w;
-      u32 cache = 64;
-      const u32 want = (u32)std::max(64, std::min(1024, env_int("HNY_GRP_CACHE", 512)));
-      while (cache * 2 <= want) cache *= 2;
-      gw.grp_cache = cache;
-      const size_t budget = (size_t)160 * 1024 / 3 - 64;
-      const size_t fixed = 4 * (hnyk_walk_grp_lds_bytes(w.rcap, 0, 0) - 64) / 4 + (size_t)4 * cache * 8;
-      gw.vis_slots = budget > fixed ? (u32)((budget - fixed) / 16 / 64 * 64) : 0u;
-      if (gw.vis_slots >= 512u) {
-        const uint32_t groups = (n + 3) / 4;
-        return hnyk_walk_grp(b->g, gw, b->shape, (int)std::min<uint32_t>(groups, std::min<uint32_t>(b->walk_slots / 4, 768u)), st);
-      }
-    }
-    const int rc = b->sub_blocks && b->ctr_used + 3 <= b->d_ctr.n ? hnyk_walk_sub_rc(b->g, w, b->shape) : 0;
-    if (!rc) return hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
-    u32 *ctr = b->d_ctr.p + b->ctr_used;
-    b->ctr_used += 3;
-    WalkArgs s4 = w;
-    s4.xcd_tile = 0; // (the four-queries-per-wave kernel and its retry launch keep the single counter)
-    s4.queue = ctr;
-    s4.vtab = b->d_vtab.p;
-    s4.vtab_slots = b->vtab_slots;
-    s4.retry = b->d_retry.p;
-    s4.force_retry = (u32)std::max(0, env_int("HNY_SUB_FORCE_RETRY", 0)); // tests: hand over every n-th member
-    s4.n_retry = ctr + 1;
-    hipError_t rc2 = hnyk_walk_sub(b->g, s4, b->shape, rc, (int)std::min<uint32_t>((n + 3) / 4, b->sub_blocks), st);
-    if (rc2 != hipSuccess) return rc2;
-    WalkArgs r = w; // retry launch: queue index -> member through the retry list
-    r.xcd_tile = 0;
-    r.lo = 0;
-    r.hi = 0;
-    r.hi_dev = ctr + 1;
-    r.perm = b->d_retry.p;
-    r.queue = ctr + 2;
-    return hnyk_walk(b->g, r, b->shape, (int)std::min<uint32_t>(n, b->walk_slots), st);
+  auto launch_walk_fast = [&](const WalkArgs &w, hipStream_t st) -> hipError_t {
+    return hnyk_walk(b->g, w, b->shape, (int)std::min<uint32_t>(w.hi - w.lo, b->walk_slots), st);
   };
   // one walk launch + its safety net: the members whose tie pool overflowed (none, normally) are listed on
   // the device and walked again by k_walk_heap, which reads the count itself — no host round trip
@@ -1736,17 +1659,11 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->entry_points = eps;
   g->n_entry_points = (uint32_t)b->entry_points.size();
   g->max_level = ml;
-  if (getenv("HNY_DEBUG_SUB"))
-    fprintf(stderr, "[hny] sub-wave walks %llu, handed over %llu (visited table full %llu, tie pool full %llu)\n",
-            stats[ST_SUB_DONE], stats[ST_SUB_RETRY], stats[ST_SUB_RETRY_VIS], stats[ST_SUB_RETRY_POOL]);
 #ifdef HNY_PHASE_CLOCKS
   fprintf(stderr, "[hny] walk wave cycles: pop %llu list+visited %llu distances %llu insert %llu | expansions %llu | whole kernel %llu\n",
           stats[ST_PH_POP], stats[ST_PH_LIST], stats[ST_PH_DIST], stats[ST_PH_INSERT], stats[ST_PH_EXPANSIONS],
           stats[ST_PH_REST]);
 #endif
-  if (getenv("HNY_DEBUG_GRP"))
-    fprintf(stderr, "[hny] grouped walk: %llu distances taken from the caches, %llu scored for partners, %llu walk evaluations\n",
-            stats[ST_GRP_HITS], stats[ST_GRP_DEPOSITS], stats[ST_EVALS_WALK]);
   if (getenv("HNY_DEBUG_COUNTS"))
     fprintf(stderr, "[hny] expansions %llu accepted %llu notfull %llu evals_walk %llu\n", stats[9], stats[10], stats[11],
             stats[ST_EVALS_WALK]);
@@ -1757,8 +1674,6 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   g->n_distance_evals = stats[ST_EVALS_WALK] + stats[ST_EVALS_PRUNE] + stats[ST_EVALS_APPLY];
   g->n_batches = b->n_batches;
   g->n_tie_pool_overflow = stats[ST_POOL_OVERFLOW];
-  g->n_sub_walks = stats[ST_SUB_DONE];
-  g->n_sub_retries = stats[ST_SUB_RETRY];
   g->t_upload_s = b->t_upload;
   g->t_build_s = b->t_build;
   g->t_export_s = now_s() - t0;

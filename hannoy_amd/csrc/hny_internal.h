@@ -34,17 +34,11 @@ enum {
   ST_ERR_RES_OVERFLOW = 6,
   ST_ERR_ITER = 7,
   ST_ERR_GAPS_OVERFLOW = 8,
-  ST_SUB_DONE = 12,  // walks completed by k_walk_sub (four queries per wave)
-  ST_SUB_RETRY = 13, // walks k_walk_sub handed over to k_walk
-  ST_SUB_RETRY_VIS = 14,  // ... because the visited table filled up
-  ST_SUB_RETRY_POOL = 15, // ... because the tie pool filled up
-  ST_GRP_HITS = 16,       // k_walk_grp: distances a member found in its cache (rows it did not load)
-  ST_GRP_DEPOSITS = 17,   // ... distances scored for partners
 #ifdef HNY_PHASE_CLOCKS // diagnostic build (HNY_CFLAGS=-DHNY_PHASE_CLOCKS): wave cycles per walk phase
-  ST_PH_POP = 18, ST_PH_LIST = 19, ST_PH_DIST = 20, ST_PH_INSERT = 21, ST_PH_EXPANSIONS = 22, ST_PH_REST = 23,
+  ST_PH_POP = 16, ST_PH_LIST = 17, ST_PH_DIST = 18, ST_PH_INSERT = 19, ST_PH_EXPANSIONS = 20, ST_PH_REST = 21,
   ST_COUNT = 24
 #else
-  ST_COUNT = 18
+  ST_COUNT = 16
 #endif
 };
 
@@ -122,18 +116,10 @@ struct WalkArgs {
   u32 vis_slots;    // LDS visited table entries per wave (0: HBM bitset only)
   u32 eps_cap;      // LDS entries of the eps array: >= max(64, n_entry_points)
   u32 key_base;     // key_out is indexed by member - key_base (== lo, except in a retry launch)
-  // k_walk_sub (four queries per wave, hny_walk_sub.h): per-query visited hash tables and the list of
-  // members it hands over to k_walk; k_walk's retry launch reads its member count from hi_dev
-  u32 *vtab;        // [grid * 4][vtab_slots], HNY_SENT = empty; every query leaves its table empty
-  u32 vtab_slots;   // power of two >= 512 (buckets of 16)
-  u64 *retry;       // members the sub-wave kernel gives up on
-  u32 force_retry;  // test hook: hand over every member with m % force_retry == 0
-  u32 *n_retry;
-  const u32 *hi_dev; // k_walk: hi = lo + *hi_dev (null: hi as given)
   const u32 *cancel; // reader mode: pinned host word, non-zero = take no further query (reader.rs:333)
   u64 *res_global;   // general kernels: result sets of more than 4 096 entries live in HBM, [grid][rcap] (else null: LDS)
   u32 xcd_tile;      // != 0: `queue` is 8 counters, one per XCD; tile k of xcd_tile members belongs to XCD k % 8
-  // Tie-pool overflow (build walks): k_walk / k_walk_sub list the member here instead of failing the build;
+  // Tie-pool overflow (build walks): k_walk lists the member here instead of failing the build;
   // k_walk_heap then redoes exactly those members with walk_layer's own data structures — `candidates` and
   // `res` as real heaps in HBM (heap_c / heap_r, [grid][cap] each), no pool, nothing to overflow but memory.
   u32 *pool_retry;   // members whose walk overflowed the 128-slot tie pool (null: count it as an error)
@@ -141,7 +127,6 @@ struct WalkArgs {
   u64 *heap_c, *heap_r;
   u32 heap_c_cap, heap_r_cap;
   u32 force_pool;    // test hook (HNY_POOL_FORCE_RETRY=n): treat every member with m % n == 0 as overflowed
-  u32 grp_cache;     // k_walk_grp: entries of a member's distance cache (a power of two)
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -229,15 +214,6 @@ struct LaunchShape {
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
 // the members of a.pool_retry[0 .. *a.n_pool_retry) again, on heaps in HBM (a.queue: its own work counter)
 hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
-// four members per workgroup with distance sharing (k_walk_grp); grid = workgroups of 4 waves
-bool hnyk_walk_grp_ok(const GraphDev &g, const WalkArgs &a, LaunchShape s);
-size_t hnyk_walk_grp_lds_bytes(u32 rcap, u32 vis_slots, u32 cache);
-hipError_t hnyk_walk_grp(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st);
-// four queries per wave (rows <= 512 B, M0 <= 32, ef <= 127, <= 32 entry points, plain fresh build);
-// rc = 16-entry chunks of the register beam the launch needs (0: not eligible)
-int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s);
-hipError_t hnyk_walk_sub(const GraphDev &g, const WalkArgs &a, LaunchShape s, int rc, int grid, hipStream_t st);
-size_t hnyk_walk_sub_lds(int rc);
 hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
@@ -275,9 +251,6 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
 // the build kernels specialised for metric N-1 (hny_kernels.hip compiled with -DHNY_PART=N)
 #define HNY_DECL_SP(N)                                                                                      \
   hipError_t hnyk_walk_sp##N(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st); \
-  hipError_t hnyk_walk_sub_sp##N(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid,          \
-                                 hipStream_t st);                                                           \
-  hipError_t hnyk_walk_grp_sp##N(const GraphDev &g, const WalkArgs &a, int nch, int grid, hipStream_t st);  \
   hipError_t hnyk_prune_wg_sp##N(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw,      \
                                  int grid, hipStream_t st);                                                 \
   hipError_t hnyk_apply_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,               \

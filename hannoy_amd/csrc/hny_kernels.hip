@@ -60,7 +60,7 @@
 
 // Lane of the calling wave.  The wave-level routines below (distances, beam, visited set, walk_one_layer)
 // run in 64-thread blocks — one wave is the workgroup, and with __launch_bounds__(64) the mask folds away —
-// and in the waves of k_walk_grp's 256-thread workgroups.
+// and in the waves of larger workgroups (the mask then selects the wave-relative lane).
 #define HNY_LANE ((int)(threadIdx.x & 63u))
 
 namespace {
@@ -613,117 +613,6 @@ __device__ __forceinline__ void dist_rows_narrow(const GraphDev &g, const float4
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Distance sharing inside a group of four neighbouring queries (k_walk_grp, rows of 1 to 3 KB).
-// Members next to each other in locality order score largely the same rows (scripts/r3_row_overlap.py:
-// 52 % of a walk's rows are also scored by the next member, 34 % by the one after; a group of four needs
-// 0.59 distinct rows per scored row), but they drift apart in time, and an XCD's 4 MB L2 holds the rows
-// of a quarter of an expansion round — so most of that reuse is lost between the L2 and the fabric.  Here
-// the four members of a group run as the four waves of one workgroup, and whoever loads a row scores it
-// for all four: its own distance goes to its beam, the other three go to the partners' distance caches
-// in LDS (direct-mapped, id << 32 | distance bits; the partner's query row is read from its LDS image).
-// A member that finds a row's distance in its cache does not load the row.  The arithmetic is the wave
-// order whoever executes it (lane t owns float4 #(c * 64 + t), one fma chain, the same butterfly), so
-// every distance has the bits the member itself would have computed: graphs stay identical, only the
-// number of rows crossing the fabric changes.  This is the "query x candidates block" of the north star
-// — four queries against the four rows a wave has in flight — kept on the VALU: the f32 chains are what
-// makes the result bit-identical to the CPU restatement.
-// ---------------------------------------------------------------------------------------------
-#ifndef HNY_GRP_CACHE_MAX
-#define HNY_GRP_CACHE_MAX 1024
-#endif
-struct NoGroup {
-  static constexpr bool on = false;
-};
-template <int NCH>
-struct GroupCtx {
-  static constexpr bool on = true;
-  float4 qp[3][NCH];    // the three partners' query rows, in registers (partner i = member (w + 1 + i) & 3)
-  float qnp[3];         // their header norms
-  volatile u32 *active; // [4] member is walking (its distance cache is live)
-  u64 *dcache;          // [4][cache] id << 32 | distance bits; ~0 = empty
-  u32 cache_mask;       // cache - 1 (a power of two)
-  u32 cache_shift;      // 32 - log2(cache)
-  u32 *ld_ids;          // [64] this wave's rows to load after the cache probe
-  u32 *ld_pos;          // [64] their positions in the caller's id list
-  int w;                // this wave's member index
-  u32 n_hit, n_dep;     // diagnostics: distances taken from the cache / deposited
-};
-
-// dist_rows for a member of a group (LPR = 64: one row per load instruction, four rows in flight)
-template <int NCH>
-__device__ __forceinline__ void dist_rows_grp(const GraphDev &g, const float4 (&q)[NCH], float qn, const u32 *ids,
-                                              int n, float *out, GroupCtx<NCH> &gx) {
-  static_assert(NCH <= 3, "four rows of at most 3 KB in registers");
-  constexpr int LPR = 64;
-  const int ln = HNY_LANE;
-  const u32 cache = gx.cache_mask + 1u;
-  // 1. what the partners already scored for this query
-  const u64 *mine = gx.dcache + (size_t)gx.w * cache;
-  const u32 id = ln < n ? ids[ln] : 0u;
-  const u64 e = ln < n ? mine[(id * 0x9E3779B1u) >> gx.cache_shift] : 0ull;
-  const bool hit = ln < n && (u32)(e >> 32) == id;
-  if (hit) out[ln] = __uint_as_float((u32)(e & 0xFFFFFFFFull));
-  const u64 miss = __ballot(ln < n && !hit);
-  const int n_ld = __popcll(miss);
-  gx.n_hit += (u32)(n - n_ld);
-  if (ln < n && !hit) {
-    const int rk = __popcll(miss & ((1ull << ln) - 1ull));
-    gx.ld_ids[rk] = id;
-    gx.ld_pos[rk] = (u32)ln;
-  }
-  WSYNC();
-  const int j4 = fold4_row<LPR>();
-  // 2. the rest: four rows per pass, each scored for every member that is still walking
-  for (int k0 = 0; k0 < n_ld; k0 += 4) {
-    float4 r[4][NCH];
-    float rn[4];
-    u32 rid[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int idx = k0 + j < n_ld ? k0 + j : n_ld - 1;
-      rid[j] = (u32)__builtin_amdgcn_readfirstlane((int)gx.ld_ids[idx]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      rn[j] = 0.f;
-      if (k0 + j < n_ld) { // wave-uniform
-        load_row<LPR, NCH>(g.rows + (size_t)rid[j] * g.row_stride, ln, g.n16, r[j]);
-        if (g.norms) rn[j] = g.norms[rid[j]];
-      } else {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) r[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    float rnj = rn[0];
-    u32 ridj = rid[0];
-#pragma unroll
-    for (int jj = 1; jj < 4; jj++) {
-      rnj = (j4 == jj) ? rn[jj] : rnj;
-      ridj = (j4 == jj) ? rid[jj] : ridj;
-    }
-    const bool writer = (ln & 15) == 0 && k0 + j4 < n_ld; // one lane per row holds that row's sum
-    {
-      const float pa = fold4<LPR, float>(partial_f32<NCH>(g.mclass, q, r[0]), partial_f32<NCH>(g.mclass, q, r[1]),
-                                         partial_f32<NCH>(g.mclass, q, r[2]), partial_f32<NCH>(g.mclass, q, r[3]));
-      const float d = finalize_f32(g, pa, qn, rnj);
-      if (writer) out[gx.ld_pos[k0 + j4]] = d;
-    }
-    const u32 cslot = (ridj * 0x9E3779B1u) >> gx.cache_shift;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int p = (gx.w + 1 + i) & 3;
-      if (!gx.active[p]) continue; // wave-uniform: that member has finished (or the group is short)
-      const float pp = fold4<LPR, float>(partial_f32<NCH>(g.mclass, gx.qp[i], r[0]), partial_f32<NCH>(g.mclass, gx.qp[i], r[1]),
-                                         partial_f32<NCH>(g.mclass, gx.qp[i], r[2]), partial_f32<NCH>(g.mclass, gx.qp[i], r[3]));
-      const float dp = finalize_f32(g, pp, gx.qnp[i], rnj);
-      if (writer) gx.dcache[(size_t)p * cache + cslot] = ((u64)ridj << 32) | (u64)fbits(dp);
-      gx.n_dep += (u32)((n_ld - k0) < 4 ? (n_ld - k0) : 4);
-    }
-  }
-  WSYNC();
-}
-
 // neighbour list of (layer, node): ids in insertion order, HNY_SENT beyond the count
 // (get_neighbours, hnsw.rs:428-456, fresh DB: in-memory lists only)
 __device__ __forceinline__ const u32 *nbr_ids(const GraphDev &g, u32 layer, u32 node, u32 &cap) {
@@ -1174,11 +1063,11 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 // LMERGE: the LDS beam (RC == 0) takes the accepted keys of an expansion in one batched merge
 // PAGED: lists of more than 64 slots (64 < M0 <= 256) are taken 64 at a time — the general kernels;
 // the specialised ones serve M0 <= 64 and keep the single pass (the loop's live values cost them 0.6 %)
-template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH, bool LMERGE = false, bool PAGED = false, class GX = NoGroup> // RC: 64-entry chunks of a register beam, 0 = LDS beam
+template <int LPR, int NCH, bool BIG_EPS, int RC = 0, int QN = NCH, bool LMERGE = false, bool PAGED = false> // RC: 64-entry chunks of a register beam, 0 = LDS beam
 __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (&q)[QN], float qn, u32 layer,
                                int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
-                               const unsigned char *qrow, BeamR<(RC ? RC : 1)> &rb, GX *gx = nullptr) {
+                               const unsigned char *qrow, BeamR<(RC ? RC : 1)> &rb) {
   constexpr bool RB = RC != 0;
   constexpr int RCN = RC ? RC : 1;
   static_assert(!(RB && BIG_EPS), "the register beam holds at most 64 * RC entries");
@@ -1202,8 +1091,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     if (BIG_EPS) WSYNC();
     if (ln < ne) nb_ids[ln] = id;
     WSYNC();
-    if constexpr (GX::on) dist_rows_grp<NCH>(g, q, qn, nb_ids, ne, nb_d, *gx);
-    else if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, ne, nb_d);
+    if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, ne, nb_d);
     else dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
     evals += (u64)ne;
     WSYNC();
@@ -1394,8 +1282,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       if (isnew) nb_ids[rank] = id;
       WSYNC();
       PH_STAMP(s, 1);
-      if constexpr (GX::on) dist_rows_grp<NCH>(g, q, qn, nb_ids, n_new, nb_d, *gx); // :503
-      else if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, n_new, nb_d);
+      if constexpr (QN != NCH) dist_rows_narrow<LPR>(g, q, qn, nb_ids, n_new, nb_d); // :503
       else dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow);
       evals += (u64)n_new;
       WSYNC();
@@ -1460,7 +1347,6 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   WalkArgs a = a_in;
   specialize<SP>(g);
   if constexpr (SP != 0) a.reader_mode = RM ? 1 : 0; // RM: the Reader's search (hny_builder_search_knn)
-  if (a.hi_dev) a.hi = a.lo + *a.hi_dev; // retry launch behind k_walk_sub: the members it gave up on
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
@@ -1720,184 +1606,6 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
     if (s.err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
     if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_walk_grp: the level-0 beam searches of a large batch, four neighbouring members per 256-thread
-// workgroup (one wave each) with distance sharing (GroupCtx above).  Serves exactly the launch the
-// locality path makes for layer 0 (eps_in from the descent launch, perm = locality order, XCD-tiled
-// queue in units of groups); everything else stays on k_walk.  The four members start together and the
-// workgroup takes its next group when all four are done (two barriers per group — none inside a walk).
-// LDS per workgroup: 64-byte header | 4 distance caches | 4 x (res, pool, frontier, eps, load list,
-// visited table) — sized by the host so that three workgroups fit a CU (12 waves: measured as fast as 16
-// for the HBM-bound walk, and 3 waves per SIMD leave 168 VGPRs for the three partner queries).
-// ---------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t walk_grp_wave_bytes(u32 rcap, u32 vis_slots) {
-  return (size_t)rcap * 8 + HNY_POOL_CAP * 8 + 64 * 4 * 2 + 64 * 4 + 64 * 4 * 2 + (size_t)vis_slots * 4;
-}
-__host__ __device__ inline size_t walk_grp_lds_bytes(u32 rcap, u32 vis_slots, u32 cache) {
-  return 64 + (size_t)4 * cache * 8 + 4 * walk_grp_wave_bytes(rcap, vis_slots);
-}
-
-template <int NCH, int SP, int RC>
-__global__ __launch_bounds__(256, 3) void k_walk_grp(GraphDev g_in, WalkArgs a_in) {
-  constexpr int LPR = 64;
-  constexpr bool RB = RC != 0;
-  constexpr int RCN = RC ? RC : 1;
-  constexpr bool LMERGE = RC == 0;
-  static_assert(SP >= 1 && SP <= 3, "f32 metrics");
-  GraphDev g = g_in;
-  WalkArgs a = a_in;
-  specialize<SP>(g);
-  a.reader_mode = 0;
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int ln = HNY_LANE, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const u32 cache = a.grp_cache;
-  volatile u32 *hdr = reinterpret_cast<volatile u32 *>(smem); // [0..3] active, [4] group index
-  u64 *dcache = reinterpret_cast<u64 *>(smem + 64);
-  unsigned char *mine = smem + 64 + (size_t)4 * cache * 8 + (size_t)w * walk_grp_wave_bytes(a.rcap, a.vis_slots);
-  u64 *res = reinterpret_cast<u64 *>(mine);
-  u64 *pool = res + a.rcap;
-  u32 *nb_ids = reinterpret_cast<u32 *>(pool + HNY_POOL_CAP);
-  float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
-  u32 *eps = reinterpret_cast<u32 *>(nb_d + 64);
-  u32 *ld_ids = eps + 64;
-  u32 *ld_pos = ld_ids + 64;
-  u32 *vtab = ld_pos + 64;
-
-  Beam s;
-#ifdef HNY_PHASE_CLOCKS
-  for (int i = 0; i < 5; i++) s.ph[i] = 0;
-  s.ph_t = 0;
-#endif
-  s.res = res;
-  s.pool = pool;
-  s.rcap = (int)a.rcap;
-  s.pool_over = 0;
-  s.err = 0;
-  s.res_len = 0;
-  s.pool_len = 0;
-  s.n_weird = 0;
-  s.tie_bits = 0;
-  s.dropped = false;
-  BeamR<RCN> rb;
-#pragma unroll
-  for (int c = 0; c < RCN; c++) rb.r[c] = 0ull;
-  if constexpr (RB) s.rcap = s.rcap < 64 * RCN ? s.rcap : 64 * RCN;
-  const size_t slot = (size_t)blockIdx.x * 4 + (size_t)w; // this wave's visited bitset / log
-  Visited vis;
-  visited_init(vis, a.bits + slot * a.bits_words, a.bits_words, a.vlog + slot * a.log_cap, a.log_cap, vtab, a.vis_slots);
-  GroupCtx<NCH> gx;
-  gx.active = hdr;
-  gx.dcache = dcache;
-  gx.cache_mask = cache - 1u;
-  gx.cache_shift = 32u - (u32)__builtin_ctz(cache);
-  gx.ld_ids = ld_ids;
-  gx.ld_pos = ld_pos;
-  gx.w = w;
-  gx.n_hit = 0;
-  gx.n_dep = 0;
-  u64 evals = 0;
-  u32 err_iter = 0, log_over_cnt = 0;
-  const u32 cnt_all = a.hi - a.lo, n_groups = (cnt_all + 3u) / 4u;
-  u32 xq_dead = 0;
-  for (;;) {
-    __syncthreads(); // the previous group is finished in every wave
-    if (threadIdx.x == 0) {
-      u32 gi = 0xFFFFFFFFu;
-      if (a.xcd_tile) { // tiles of xcd_tile / 4 consecutive groups go round-robin to the XCDs (see k_walk)
-        const u32 T = a.xcd_tile / 4u;
-        while (xq_dead < 8u) {
-          const u32 x = (blockIdx.x + xq_dead) & 7u;
-          const u32 c = atomicAdd(a.queue + x, 1u);
-          const u32 idx = ((c / T) * 8u + x) * T + (c % T);
-          if (idx < n_groups) {
-            gi = idx;
-            break;
-          }
-          xq_dead++;
-        }
-      } else {
-        const u32 c = atomicAdd(a.queue, 1u);
-        if (c < n_groups) gi = c;
-      }
-      hdr[4] = gi;
-    }
-    __syncthreads();
-    const u32 gi = hdr[4];
-    if (gi == 0xFFFFFFFFu) break;
-    // the four members of the group, in processing order
-    u32 mem[4];
-    bool have[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const u32 mi = gi * 4u + (u32)p;
-      have[p] = mi < cnt_all;
-      const u32 mq = have[p] ? mi : gi * 4u;
-      mem[p] = a.perm ? uni((u32)a.perm[mq]) : a.lo + mq; // results stay indexed by member
-    }
-    u32 m = mem[0];
-    bool mine_on = have[0];
-#pragma unroll
-    for (int p = 1; p < 4; p++) {
-      m = w == p ? mem[p] : m;
-      mine_on = w == p ? have[p] : mine_on;
-    }
-    const u32 qslot = a.q_slots[m];
-    const unsigned char *qrow = g.rows + (size_t)qslot * g.row_stride;
-    const float qn = g.norms ? g.norms[qslot] : 0.f;
-    float4 q[NCH];
-    load_row<LPR, NCH>(qrow, ln, g.n16, q);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      u32 mp = mem[1];
-#pragma unroll
-      for (int p = 0; p < 4; p++) mp = ((w + 1 + i) & 3) == p ? mem[p] : mp;
-      const u32 ps = a.q_slots[mp];
-      load_row<LPR, NCH>(g.rows + (size_t)ps * g.row_stride, ln, g.n16, gx.qp[i]);
-      gx.qnp[i] = g.norms ? g.norms[ps] : 0.f;
-    }
-    for (u32 i = (u32)ln; i < cache; i += 64u) dcache[(size_t)w * cache + i] = ~0ull;
-    if (ln == 0) hdr[w] = mine_on ? 1u : 0u;
-    __syncthreads();
-    if (mine_on) {
-      const u64 evals_before = evals;
-      if (ln == 0) eps[0] = a.eps_in[m];
-      WSYNC();
-      walk_one_layer<LPR, NCH, false, RC, NCH, LMERGE, false, GroupCtx<NCH>>(g, q, qn, a.layer, (int)a.ef, eps, 1, s, vis, nb_ids,
-                                                                              nb_d, evals, err_iter, qrow, rb, &gx);
-      if (ln == 0) hdr[w] = 0u; // partners stop scoring for this member
-      if (a.force_pool && m % a.force_pool == 0u) s.pool_over = 1u;
-      if (s.pool_over && a.pool_retry) { // see k_walk: k_walk_heap redoes this member
-        if (ln == 0) a.pool_retry[atomicAdd(a.n_pool_retry, 1u)] = m;
-        s.pool_over = 0;
-        evals = evals_before;
-      }
-      if constexpr (RB) {
-#pragma unroll
-        for (int c = 0; c < RCN; c++)
-          if (ln + 64 * c < s.res_len)
-            a.cand[(size_t)m * a.rcap + 64 * c + ln] = (rb.r[c] & 0xFFFFFFFF00000000ull) | ((rb.r[c] >> 1) & 0x7FFFFFFFull);
-      } else {
-        for (int e = ln; e < s.res_len; e += 64) {
-          const u64 k = s.res[e];
-          a.cand[(size_t)m * a.rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
-        }
-      }
-      if (ln == 0) a.cand_n[m] = (u32)s.res_len;
-      if (vis.log_over) log_over_cnt++;
-      visited_clear(vis);
-    }
-  }
-  if (ln == 0) {
-    if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
-    if (s.pool_over) atomicAdd(&g.stats[ST_POOL_OVERFLOW], (u64)s.pool_over);
-    if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
-    if (s.err) atomicAdd(&g.stats[ST_ERR_RES_OVERFLOW], 1ull);
-    if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
-    if (gx.n_hit) atomicAdd(&g.stats[ST_GRP_HITS], (u64)gx.n_hit);
-    if (gx.n_dep) atomicAdd(&g.stats[ST_GRP_DEPOSITS], (u64)gx.n_dep);
   }
 }
 
@@ -3668,7 +3376,6 @@ __global__ void k_fill_u32(u32 *p, u32 v, size_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
-#include "hny_walk_sub.h"
 
 template <template <int, int> class Launcher, typename... Args>
 hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
@@ -3727,48 +3434,6 @@ struct Hot {
       return hipGetLastError();
     }
   };
-  // four members per workgroup with distance sharing (k_walk_grp): rows of 2 or 3 sixteen-byte chunks per lane
-  static hipError_t walk_grp(const GraphDev &g, const WalkArgs &a, int nch, int grid, hipStream_t st) {
-    if constexpr (SP < 1 || SP > 3) {
-      return hipErrorInvalidValue;
-    } else {
-      const size_t lds = walk_grp_lds_bytes(a.rcap, a.vis_slots, a.grp_cache);
-      const bool rb = a.rcap <= 128;
-#define HNY_GRP_CASE(C, R)                                                                            \
-  if (nch == C && rb == (R != 0)) {                                                                   \
-    hipLaunchKernelGGL((k_walk_grp<C, SP, R>), dim3(grid), dim3(256), lds, st, g, a);                 \
-    return hipGetLastError();                                                                         \
-  }
-      HNY_GRP_CASE(2, 2)
-      HNY_GRP_CASE(2, 0)
-      HNY_GRP_CASE(3, 2)
-      HNY_GRP_CASE(3, 0)
-#undef HNY_GRP_CASE
-      return hipErrorInvalidValue;
-    }
-  }
-  static hipError_t walk_sub(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid, hipStream_t st) {
-    if constexpr (SP == 0) {
-      return hipErrorInvalidValue;
-    } else {
-#define HNY_SUB_CASE(L, R)                                                                                   \
-  if (lpro == L && rc == R) {                                                                                \
-    hipLaunchKernelGGL((k_walk_sub<L, R, SP>), dim3(grid), dim3(64), walk_sub_lds_bytes(R), st, g, a);       \
-    return hipGetLastError();                                                                                \
-  }
-      HNY_SUB_CASE(8, 4)
-      HNY_SUB_CASE(8, 7)
-      HNY_SUB_CASE(8, 8)
-      HNY_SUB_CASE(16, 4)
-      HNY_SUB_CASE(16, 7)
-      HNY_SUB_CASE(16, 8)
-      HNY_SUB_CASE(32, 4)
-      HNY_SUB_CASE(32, 7)
-      HNY_SUB_CASE(32, 8)
-#undef HNY_SUB_CASE
-      return hipErrorInvalidValue;
-    }
-  }
   template <int L, int C>
   struct PruneWg {
     static hipError_t run(const GraphDev &g, const PruneArgs &a, int SL, int nw, int grid, hipStream_t st) {
@@ -3912,13 +3577,6 @@ hipError_t HNY_CAT(hnyk_walk_sp, HNY_PART)(const GraphDev &g, const WalkArgs &a,
                                            hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::Walk>(s, g, a, grid, st);
 }
-hipError_t HNY_CAT(hnyk_walk_sub_sp, HNY_PART)(const GraphDev &g, const WalkArgs &a, int lpro, int rc, int grid,
-                                               hipStream_t st) {
-  return Hot<HNY_PART>::walk_sub(g, a, lpro, rc, grid, st);
-}
-hipError_t HNY_CAT(hnyk_walk_grp_sp, HNY_PART)(const GraphDev &g, const WalkArgs &a, int nch, int grid, hipStream_t st) {
-  return Hot<HNY_PART>::walk_grp(g, a, nch, grid, st);
-}
 hipError_t HNY_CAT(hnyk_prune_wg_sp, HNY_PART)(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL,
                                                int nw, int grid, hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::PruneWg>(s, g, a, SL, nw, grid, st);
@@ -3958,34 +3616,6 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap) {
 hipError_t hnyk_walk(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
   if (fast_path(g) && a.eps_cap <= 64 && !a.res_global) { HNY_SP_SWITCH(hnyk_walk_sp, g, a, s, grid, st) }
   return dispatch_shape<Hot<0>::Walk>(s, g, a, grid, st);
-}
-size_t hnyk_walk_grp_lds_bytes(u32 rcap, u32 vis_slots, u32 cache) { return walk_grp_lds_bytes(rcap, vis_slots, cache); }
-bool hnyk_walk_grp_ok(const GraphDev &g, const WalkArgs &a, LaunchShape s) {
-  // the plain build's level-0 launch of the locality path on 2 / 3 KB f32 rows, beam of at most 256 entries
-  return fast_path(g) && g.metric <= 2 && s.lpr == 64 && (s.nch == 2 || s.nch == 3) && a.eps_in && !a.first &&
-         !a.descend_only && a.layer == 0 && a.rcap <= 256 && a.eps_cap <= 64 && !a.res_global && !a.q_rows && !a.hi_dev;
-}
-hipError_t hnyk_walk_grp(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
-  switch (g.metric) {
-    case 0: return hnyk_walk_grp_sp1(g, a, s.nch, grid, st);
-    case 1: return hnyk_walk_grp_sp2(g, a, s.nch, grid, st);
-    default: return hnyk_walk_grp_sp3(g, a, s.nch, grid, st);
-  }
-}
-int hnyk_walk_sub_rc(const GraphDev &g, const WalkArgs &a, LaunchShape s) {
-  // opt-in (HNY_SUB=1; read per launch: tests flip it inside one process): exact, but measured no faster
-  // than one wave per query — both issue the same ~35-45 VALU instructions per evaluation, because the
-  // O(ef) beam maintenance per expansion does not shrink with the lanes a query owns
-  const char *e = getenv("HNY_SUB");
-  if (!e || atoi(e) == 0) return 0;
-  if (!fast_path(g) || a.reader_mode || a.q_rows || s.nch != 1 || s.lpr > 32) return 0;
-  if (g.M0 > 32 || g.M > 32 || a.n_entry_points > 32 || a.cap_sel > 32) return 0;
-  const u32 need = a.ef > 32 ? a.ef : 32; // res holds max(ef, entry points) keys
-  return need <= 64 ? 4 : (need <= 112 ? 7 : (need <= 128 ? 8 : 0));
-}
-size_t hnyk_walk_sub_lds(int rc) { return walk_sub_lds_bytes(rc); }
-hipError_t hnyk_walk_sub(const GraphDev &g, const WalkArgs &a, LaunchShape s, int rc, int grid, hipStream_t st) {
-  HNY_SP_SWITCH(hnyk_walk_sub_sp, g, a, s.lpr, rc, grid, st)
 }
 hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<WalkHeapLauncher>(s, g, a, grid, st);

@@ -130,9 +130,6 @@ typedef struct {
    * hny_builder_set_profiling(b, 1) (else 0) */
   double t_walk_kernels_s, t_prune_kernels_s, t_sort_kernels_s, t_apply_kernels_s;
   uint64_t n_walk_launches;
-  /* walks (one per member and launch) finished by the four-queries-per-wave kernel / handed over by
-   * it to the one-wave kernel (hny_walk_sub.h); both 0 when rows are longer than 512 B */
-  uint64_t n_sub_walks, n_sub_retries;
 } hny_graph;
 
 typedef struct hny_builder hny_builder;

@@ -12,5 +12,4 @@ run() { # name
   find $out -name "*.csv" -delete
   echo "== $name"; cat $out/$name.txt
 }
-HNY_SUB=0 run ${NAME:-c5}_classic
-[ -n "$ONLY_CLASSIC" ] || HNY_SUB=1 run ${NAME:-c5}_sub
+run ${NAME:-c5}_classic

@@ -12,6 +12,5 @@ run() { # name
   grep -a '"metric"' $out/$name.log | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('   bench: walk', j['build']['t_walk_kernels_s'], 's, value', j['value'])" >> $out/summary.txt
   find $out/$name -name "*.csv" -delete
 }
-HNY_SUB=1 run sub
-HNY_SUB=0 run classic
+run classic
 cat $out/summary.txt

@@ -5,7 +5,7 @@ import collections, csv, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    fam = next((k for k in ("k_walk_sub", "k_walk", "k_prune_wg", "k_apply_wg", "k_apply", "k_emit", "k_segments") if k in n), "other")
+    fam = next((k for k in ("k_walk_heap", "k_walk", "k_prune_wg", "k_apply_wg", "k_apply", "k_emit", "k_segments") if k in n), "other")
     agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
 for fam, c in agg.items():
     wc = c.get("SQ_WAVE_CYCLES", 0) or 1

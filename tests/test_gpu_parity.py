@@ -407,59 +407,6 @@ def test_mass_deletion_fill_gaps_worst_case(orc, hny, M, M0, keep_frac):
     assert {i for (i, l) in d if l == 0} == alive
 
 
-SUB_CASES = [
-    # metric, n, dim, M, M0, ef  (rows <= 512 B, M0 <= 32, ef <= 127: the four-queries-per-wave walk)
-    (0, 6000, 128, 16, 32, 100),   # C4's shape: 512-B rows, LPRO 32, 7-chunk beam
-    (3, 8000, 1024, 16, 32, 64),   # C5's shape: 128-B codes, LPRO 8, 4-chunk beam, ties everywhere
-    (1, 5000, 60, 12, 24, 40),     # 240-B rows, LPRO 16
-    (4, 4000, 700, 8, 16, 120),    # BQ-cosine (negative "weird" distances), 8-chunk beam
-    (2, 3000, 20, 5, 9, 33),       # odd caps (list positions 2t / 2t + 1 past an odd end)
-    (5, 3000, 2000, 16, 32, 64),   # 256-B codes
-]
-
-
-@pytest.mark.parametrize("metric,n,dim,M,M0,ef", SUB_CASES)
-@pytest.mark.parametrize("variant", ["default", "hand_over", "tiny_tables", "one_block"])
-def test_sub_wave_walk_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, ef, variant):
-    """k_walk_sub (four queries per wave) against the oracle, edge for edge, with the same number of
-    walk evaluations; `hand_over` makes the kernel give up on every third member (what a full tie
-    pool does) so that the retry launch of the one-wave kernel computes those members; `one_block` runs every query through a single wave's
-    four sub-waves (queue refill, table reuse); the default path (one wave per query) must build the
-    same graph."""
-    monkeypatch.setenv("HNY_SUB", "1")  # opt-in path (measured no faster than one wave per query)
-    if variant == "hand_over":
-        monkeypatch.setenv("HNY_SUB_FORCE_RETRY", "3")
-    if variant == "tiny_tables":  # 32 buckets: full buckets, overflow into the next one, 3/4-full hand-overs
-        monkeypatch.setenv("HNY_SUB_VSLOTS", "512")
-    if variant == "one_block":
-        monkeypatch.setenv("HNY_SUB_BLOCKS", "1")
-    rng = np.random.default_rng(n + dim)
-    if variant in ("hand_over", "tiny_tables") and metric < 3:  # nothing is ever pruned: every walk visits ~ ef * M0 items
-        vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
-    else:
-        cent = rng.uniform(-1, 1, (40, dim)).astype(np.float32)
-        vecs = (cent[rng.integers(0, 40, n)] + (0.5 if metric >= 3 else 0.15) *
-                rng.standard_normal((n, dim))).astype(np.float32)
-        vecs[rng.integers(0, n, n // 20)] = vecs[rng.integers(0, n, n // 20)]  # exact duplicates
-    levels = draw_levels(n, M, seed=n)
-    ds, items = _mk(orc, hny, metric, vecs, levels)
-    kw = dict(batch_frac=0.25, batch_max=4096)
-    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
-    g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
-    assert g.n_tie_pool_overflow == 0
-    _same_graph(g, o)
-    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
-    assert g.n_sub_walks + g.n_sub_retries > n  # every walk went through the four-queries-per-wave kernel
-    if variant == "hand_over":
-        assert g.n_sub_retries > n // 4  # ... and the retry launch had real work
-    elif variant != "tiny_tables":
-        assert g.n_sub_retries * 20 < g.n_sub_walks
-        monkeypatch.setenv("HNY_SUB", "0")
-        g1 = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
-        _same_graph(g1, o)
-        assert g1.n_evals_walk == o.n_evals_walk and g1.n_sub_walks == 0
-
-
 def test_visited_log_overflow_fallback(orc, hny, monkeypatch):
     """With a tiny visited log every walk overflows it and clears its whole bitset instead: same graph."""
     monkeypatch.setenv("HNY_VISITED_LOG", "1024")
@@ -1152,33 +1099,6 @@ def test_xcd_tiled_walk_queue_equals_oracle(orc, hny, monkeypatch, metric, n, di
     g = hny.build(items, M=16, M0=32, ef_construction=48, **kw)
     _same_graph(g, o)
     assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
-
-
-@pytest.mark.parametrize("metric,n,dim,ef,cache,every", [(0, 20000, 520, 40, 512, 0), (1, 18000, 700, 150, 64, 0),
-                                                         (2, 17000, 300, 32, 1024, 0), (0, 17000, 768, 24, 256, 5)])
-def test_grouped_walk_equals_oracle(orc, hny, monkeypatch, metric, n, dim, ef, cache, every):
-    """k_walk_grp: the level-0 walks of a batch of >= 8 192 members on 2 / 3 KB f32 rows run four neighbouring
-    members per workgroup, every loaded row scored for all four and the partners' distances left in their
-    LDS caches.  Whoever computes a distance computes it in the wave order, so graph, link count and walk
-    evaluations stay the oracle's — for register beams (ef <= 127) and LDS beams (ef = 150), tiny (64-entry)
-    and large caches, short last groups (n not a multiple of 4), and with members handed to k_walk_heap
-    (HNY_POOL_FORCE_RETRY); HNY_GRP=0 (one wave per member, no sharing) builds the same graph."""
-    monkeypatch.setenv("HNY_GRP_CACHE", str(cache))
-    if every:
-        monkeypatch.setenv("HNY_POOL_FORCE_RETRY", str(every))
-    rng = np.random.default_rng(n + dim)
-    cent = rng.uniform(-1, 1, (24, dim)).astype(np.float32)
-    vecs = (cent[rng.integers(0, 24, n)] + 0.2 * rng.standard_normal((n, dim))).astype(np.float32)
-    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, 8, seed=5))
-    kw = dict(batch_frac=1.0, batch_max=8193)
-    o = orc.build(ds, M=8, M0=16, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
-    g = hny.build(items, M=8, M0=16, ef_construction=ef, **kw)
-    _same_graph(g, o)
-    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
-    monkeypatch.setenv("HNY_GRP", "0")
-    g0 = hny.build(items, M=8, M0=16, ef_construction=ef, **kw)
-    _same_graph(g0, o)
-    assert g0.n_evals_walk == o.n_evals_walk
 
 
 def _tie_pool_fixture(orc, hny):
