@@ -1189,6 +1189,11 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     return p;
   };
   auto launch_prune = [&](const PruneArgs &p, hipStream_t st) -> hipError_t {
+    if (!b->wave_prune_only && hnyk_prune_n8_ok(b->g, p, b->shape)) {
+      // short rows: one wave per query; as many selected rows staged as 6 KB per wave hold (20 waves per CU)
+      const int sl = (int)std::min<uint32_t>(HNY_MAX_CAP, std::max<uint32_t>(1, 6144u / b->g.row_stride));
+      return hnyk_prune_n8(b->g, p, b->shape, sl, (int)std::min<uint32_t>(p.hi - p.lo, 5120u), st);
+    }
     if (b->wave_prune_only)
       return hnyk_prune(b->g, p, b->shape, (int)std::min<uint32_t>(p.hi - p.lo, b->walk_slots), st);
     return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, b->prune_nw, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
@@ -1920,6 +1925,11 @@ struct SearchCancel {
 static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, size_t qstride,
                            const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
                            float *out_dists, uint32_t *out_counts, const hny_query_opts *qo);
+// the QueryBuilder searcher with its search queue as a real heap in HBM (k_nns_filtered); force_heap: also
+// for queries without a candidates filter — where search_knn_impl sends the queries whose tie pool overflowed
+static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const void *qvectors, size_t qstride,
+                    const void *qheaders, const uint32_t *query_items, uint32_t *out_ids, float *out_dists,
+                    uint32_t *out_counts, bool force_heap);
 
 int hny_builder_search_knn(hny_builder *b, uint64_t nq, const void *qvectors, size_t qstride,
                            const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
@@ -2017,6 +2027,7 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.eps_cap = eps_cap_of(b);
     w.queue = queues;
     w.cancel = sc.d;
+    w.pool_flag = (ef + 1 <= HNY_RES_LDS_MAX && env_int("HNY_NO_POOL_RETRY", 0) == 0) ? 1u : 0u;
     if (sc.d) HIP_TRY(hnyk_fill_u32(dcn.p, 0xFFFFFFFFu, cnt, b->stream)); // = never finished
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
@@ -2050,9 +2061,14 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
     HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(sc.wait(b));
+    std::vector<uint32_t> again; // queries whose tie pool overflowed (short codes, large ef_search: ties everywhere)
     for (uint32_t i = 0; i < cnt; i++) { // drain_asc().take(k), reader.rs:797-798
       if (sc.d && hn[i] == 0xFFFFFFFFu) { // the batch was cancelled before this query finished
         out_counts[q0 + i] = 0u;
+        continue;
+      }
+      if (hn[i] == 0xFFFFFFFEu) {
+        again.push_back(i);
         continue;
       }
       uint32_t c = std::min<uint32_t>(k, hn[i]);
@@ -2063,6 +2079,36 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
         memcpy(&out_dists[(q0 + i) * k + j], &db, 4);
       }
       out_counts[q0 + i] = c;
+    }
+    if (!again.empty() && !sc.cancelled) {
+      // the same queries on the searcher whose queue is a real heap in HBM: nothing to overflow, same results
+      const size_t na = again.size();
+      std::vector<unsigned char> av(na * vb), ah(na * hb);
+      std::vector<uint32_t> ai(na * k), ac(na);
+      std::vector<float> ad(na * k);
+      for (size_t j = 0; j < na; j++) {
+        memcpy(&av[j * vb], (const unsigned char *)qvectors + (q0 + again[j]) * qstride, vb);
+        memcpy(&ah[j * hb], (const unsigned char *)qheaders + (q0 + again[j]) * hb, hb);
+      }
+      hny_query_opts o2{};
+      o2.k = k;
+      o2.ef_search = ef_search;
+      o2.linear_below = 1000;
+      o2.linear_below_ratio = 1.0f;
+      if (qo) {
+        o2.cancel = qo->cancel;
+        o2.cancel_ctx = qo->cancel_ctx;
+      }
+      int rc2 = nns_impl(b, &o2, na, av.data(), vb, ah.data(), nullptr, ai.data(), ad.data(), ac.data(), true);
+      if (rc2) return rc2;
+      for (size_t j = 0; j < na; j++) {
+        const uint64_t qi = q0 + again[j];
+        out_counts[qi] = ac[j];
+        memcpy(&out_ids[qi * k], &ai[j * k], (size_t)k * 4);
+        memcpy(&out_dists[qi * k], &ad[j * k], (size_t)k * 4);
+      }
+    } else {
+      for (uint32_t i : again) out_counts[q0 + i] = 0u;
     }
   }
   if (sc.cancelled && qo && qo->did_cancel) *qo->did_cancel = 1;
@@ -2081,6 +2127,12 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
 int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const void *qvectors,
                     size_t qstride, const void *qheaders, const uint32_t *query_items, uint32_t *out_ids,
                     float *out_dists, uint32_t *out_counts) {
+  return nns_impl(b, qo, nq, qvectors, qstride, qheaders, query_items, out_ids, out_dists, out_counts, false);
+}
+
+static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const void *qvectors, size_t qstride,
+                    const void *qheaders, const uint32_t *query_items, uint32_t *out_ids, float *out_dists,
+                    uint32_t *out_counts, bool force_heap) {
   if (!b || !qo || !out_ids || !out_dists || !out_counts || qo->k == 0)
     return fail(HNY_ERR_INVALID_ARG, "bad argument");
   const bool by_item = query_items != nullptr;
@@ -2089,7 +2141,7 @@ int hny_builder_nns(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     return fail(HNY_ERR_INVALID_ARG, "candidates missing");
   if (!(qo->linear_below_ratio >= 0.f && qo->linear_below_ratio <= 1.f)) // reader.rs:253-256
     return fail(HNY_ERR_INVALID_ARG, "linear scan threshold ratio must be between 0.0 and 1.0");
-  if (!qo->has_candidates && !by_item)
+  if (!qo->has_candidates && !by_item && !force_heap)
     return search_knn_impl(b, nq, qvectors, qstride, qheaders, qo->k, qo->ef_search, out_ids, out_dists,
                            out_counts, qo);
   if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");

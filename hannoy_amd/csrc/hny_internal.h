@@ -127,6 +127,8 @@ struct WalkArgs {
   u64 *heap_c, *heap_r;
   u32 heap_c_cap, heap_r_cap;
   u32 force_pool;    // test hook (HNY_POOL_FORCE_RETRY=n): treat every member with m % n == 0 as overflowed
+  u32 pool_flag;     // reader mode: a query whose tie pool overflowed reports cand_n = 0xFFFFFFFE (the host
+                     // repeats it on the heap-queue searcher) instead of counting an error
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,
@@ -224,6 +226,9 @@ hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int 
 hipError_t hnyk_apply_append(const GraphDev &g, const ApplyArgs &a, hipStream_t st);
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st);
+// robust_prune for rows <= 512 B: one wave per query, 8 candidates at a time (SL = selected rows staged in LDS)
+bool hnyk_prune_n8_ok(const GraphDev &g, const PruneArgs &a, LaunchShape s);
+hipError_t hnyk_prune_n8(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid, hipStream_t st);
 hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,
                             u32 stride, hipStream_t st);
 hipError_t hnyk_sort_u32(void *temp, size_t &temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st);
@@ -253,6 +258,8 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
   hipError_t hnyk_walk_sp##N(const GraphDev &g, const WalkArgs &a, LaunchShape s, int grid, hipStream_t st); \
   hipError_t hnyk_prune_wg_sp##N(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw,      \
                                  int grid, hipStream_t st);                                                 \
+  hipError_t hnyk_prune_n8_sp##N(const GraphDev &g, const PruneArgs &a, int lpro, int SL, int grid,         \
+                                 hipStream_t st);                                                           \
   hipError_t hnyk_apply_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,               \
                               hipStream_t st);                                                              \
   hipError_t hnyk_apply_wg_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid,    \

@@ -1586,6 +1586,14 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       }
       WSYNC();
     }
+    if constexpr (RM || SP == 0) {
+      // a search whose tie pool overflowed: flagged instead of counted, the host repeats the query on the
+      // heap-queue searcher (k_nns_filtered without a filter), which has no pool
+      if (a.reader_mode && a.pool_flag && s.pool_over) {
+        total = (int)0xFFFFFFFEu;
+        s.pool_over = 0;
+      }
+    }
     if (ln == 0) a.cand_n[m] = (u32)total;
     if (vis.log_over) log_over_cnt++;
     visited_clear(vis);
@@ -2558,6 +2566,160 @@ __global__ __launch_bounds__(NW * 64, wg_waves_per_simd(NCH, NW)) void k_prune_w
 }
 
 // ---------------------------------------------------------------------------------------------
+// robust_prune for SHORT rows (at most 32 sixteen-byte units = 512 B: 128-d f32, 1024-bit codes): one
+// wave per query and EIGHT candidates at a time, one per 8-lane group.  k_prune_wg gives every candidate
+// a whole wave and pays 1-3 workgroup barriers per 4 candidates: on C4 / C5 it sat 5x / 15x above the
+// time its candidate rows take to stream (384 ms and 107 ms of those builds).  Here a chunk is
+//   (1) eight candidate rows in registers (one wave-wide load brings eight 128-B rows), prefetched a
+//       chunk ahead;
+//   (2) every group scores its candidate against the selected rows, which all groups read from the
+//       wave's LDS stage at the same address (a broadcast), until every group has its answer;
+//   (3) the survivors are taken in candidate order: the first joins S, the others are scored against
+//       that one new row, and so on — `exists i in S: bits(d(c, i) * alpha) < bits(d(c, q))` does not
+//       depend on the order in which S is scanned, so this is the sequential outcome (hnsw.rs:577-592).
+// No workgroup barrier anywhere; the wave order of a 16- / 32-lane row is computed by 8 lanes exactly
+// as dist_rows_narrow does (unit partials added in the butterfly's own order).
+// ---------------------------------------------------------------------------------------------
+template <int LPRO>
+__device__ __forceinline__ float dist8(const GraphDev &g, const float4 (&c)[LPRO / 8], const float4 (&r)[LPRO / 8],
+                                       float cn, float rn) {
+  constexpr int NQ = LPRO / 8;
+  if (g.mclass == MC_BIN) return finalize_bin(g, butterfly_u32<8>(partial_bin<NQ>(c, r)), cn, rn);
+  float pu[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const float4 ck[1] = {c[k]}, rk[1] = {r[k]};
+    pu[k] = partial_f32<1>(g.mclass, ck, rk);
+  }
+  float pa;
+  if constexpr (NQ == 4) pa = (pu[0] + pu[2]) + (pu[1] + pu[3]); // off = 16, then off = 8
+  else if constexpr (NQ == 2) pa = pu[0] + pu[1];                // off = 8
+  else pa = pu[0];
+  return finalize_f32(g, butterfly_f32<8>(pa), cn, rn);
+}
+__host__ __device__ inline size_t prune_n8_lds_bytes(u32 rcap, u32 row_stride, int SL) {
+  return (size_t)rcap * 8 + (size_t)HNY_MAX_CAP * (8 + 4 + 4) + (size_t)(SL + 1) * row_stride;
+}
+
+template <int LPRO, int SP>
+__global__ __launch_bounds__(64, 5) void k_prune_n8(GraphDev g_in, PruneArgs a, int SL) {
+  static_assert(LPRO == 8 || LPRO == 16 || LPRO == 32, "rows of at most 32 units, 8 lanes each");
+  constexpr int NQ = LPRO / 8;
+  GraphDev g = g_in;
+  specialize<SP>(g);
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *list = reinterpret_cast<u64 *>(smem);
+  u64 *S = list + a.rcap;
+  u32 *s_ids = reinterpret_cast<u32 *>(S + HNY_MAX_CAP);
+  float *s_norm = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP);
+  unsigned char *stage = reinterpret_cast<unsigned char *>(s_norm + HNY_MAX_CAP); // [SL] selected rows
+  unsigned char *newrow = stage + (size_t)SL * g.row_stride;                      // the row that has just joined S
+  const int ln = HNY_LANE, t = ln & 7, gidx = ln >> 3;
+  const int cap = (int)a.cap;
+  u64 evals = 0;
+  auto load8 = [&](const unsigned char *row, float4 (&r)[NQ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      const u32 f = (u32)(k * 8 + t);
+      r[k] = f < g.n16 ? *reinterpret_cast<const float4 *>(row + (size_t)f * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto load8_lds = [&](const unsigned char *row, float4 (&r)[NQ]) __attribute__((always_inline)) {
+    const unsigned lp = (unsigned)(size_t)row;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      const u32 f = (u32)(k * 8 + t);
+      if (f < g.n16) {
+        const f32x4_t v = *reinterpret_cast<lds_cf4 *>((size_t)(lp + f * 16u));
+        r[k] = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
+    const u32 m = a.perm ? (u32)a.perm[mi - a.lo] : mi; // same locality order as the walk
+    const int n = (int)a.cand_n[m];
+    for (int e = ln; e < n; e += 64) list[e] = a.cand[(size_t)m * a.rcap + e];
+    WSYNC();
+    int s_len = 0;
+    float4 nxt[NQ];
+    float nxt_n = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) nxt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gidx < n) {
+      const u32 c0 = (u32)(list[gidx] & 0xFFFFFFFFull);
+      load8(g.rows + (size_t)c0 * g.row_stride, nxt);
+      if (g.norms) nxt_n = g.norms[c0];
+    }
+    for (int base = 0; base < n && s_len < cap; base += 8) {
+      const int ci = base + gidx;
+      const bool have = ci < n;
+      float4 c[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; k++) c[k] = nxt[k];
+      const float cn = nxt_n;
+      const u64 ck = have ? list[ci] : 0ull;
+      const u32 cid = (u32)(ck & 0xFFFFFFFFull), cdb = (u32)(ck >> 32);
+      if (ci + 8 < n) { // the next chunk's rows travel while this one is scored
+        const u32 nx = (u32)(list[ci + 8] & 0xFFFFFFFFull);
+        load8(g.rows + (size_t)nx * g.row_stride, nxt);
+        if (g.norms) nxt_n = g.norms[nx];
+      }
+      // (2) against S as it stands
+      bool viol = false;
+      for (int j = 0; j < s_len; j++) {
+        const u64 open = __ballot(have && !viol);
+        if (!open) break;
+        float4 r[NQ];
+        if (j < SL) load8_lds(stage + (size_t)j * g.row_stride, r);
+        else load8(g.rows + (size_t)s_ids[j] * g.row_stride, r); // beyond the stage (rare): from L2
+        const float d = dist8<LPRO>(g, c, r, cn, s_norm[j]);
+        viol = viol || fbits(d * g.alpha) < cdb; // hnsw.rs:585
+        evals += (u64)(__popcll(open) >> 3);
+      }
+      // (3) the survivors, in candidate order
+      u64 sv = __ballot(have && !viol && t == 0);
+      while (sv && s_len < cap) {
+        const int l1 = __ffsll((long long)sv) - 1, g1 = l1 >> 3;
+        sv &= sv - 1ull;
+        if (ln == l1) { // :591 S.push(c)
+          S[s_len] = ck;
+          s_ids[s_len] = cid;
+          s_norm[s_len] = cn;
+        }
+        if (gidx == g1) {
+#pragma unroll
+          for (int k = 0; k < NQ; k++) {
+            const u32 f = (u32)(k * 8 + t);
+            if (f < g.n16) {
+              *reinterpret_cast<float4 *>(newrow + (size_t)f * 16) = c[k];
+              if (s_len < SL) *reinterpret_cast<float4 *>(stage + (size_t)s_len * g.row_stride + (size_t)f * 16) = c[k];
+            }
+          }
+        }
+        WSYNC();
+        if (sv) { // the later survivors against the row that has just joined
+          float4 r[NQ];
+          load8_lds(newrow, r);
+          const float d = dist8<LPRO>(g, c, r, cn, s_norm[s_len]);
+          const bool out = fbits(d * g.alpha) < cdb;
+          evals += (u64)__popcll(sv);
+          sv &= ~__ballot(out && t == 0);
+          WSYNC(); // newrow is rewritten by the next selection
+        }
+        s_len++;
+      }
+    }
+    u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
+    if (ln == 0) out[0] = (u64)s_len;
+    if (ln < s_len) out[1 + ln] = S[ln];
+    WSYNC();
+  }
+  if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_PRUNE], evals);
+}
+
+// ---------------------------------------------------------------------------------------------
 // link ops.  For batch member m (in batch order), layer l from its level down to 0, k-th selected
 // (d, n): LINK(q,(d,n),l) then LINK(n,(d,q),l) (hnsw.rs:316-324).  key = layer:4 | target:31 |
 // seq:29 — a full 64-bit sort groups ops by target and keeps the reference's sequential order
@@ -3462,6 +3624,19 @@ struct Hot {
       }
     }
   };
+  // short rows (<= 512 B): one wave per query, eight candidates at a time (k_prune_n8)
+  static hipError_t prune_n8(const GraphDev &g, const PruneArgs &a, int lpro, int SL, int grid, hipStream_t st) {
+    if constexpr (SP == 0) {
+      return hipErrorInvalidValue;
+    } else {
+      const size_t lds = prune_n8_lds_bytes(a.rcap, g.row_stride, SL);
+      if (lpro == 8) hipLaunchKernelGGL((k_prune_n8<8, SP>), dim3(grid), dim3(64), lds, st, g, a, SL);
+      else if (lpro == 16) hipLaunchKernelGGL((k_prune_n8<16, SP>), dim3(grid), dim3(64), lds, st, g, a, SL);
+      else if (lpro == 32) hipLaunchKernelGGL((k_prune_n8<32, SP>), dim3(grid), dim3(64), lds, st, g, a, SL);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    }
+  }
   template <int L, int C>
   struct ApplyWg {
     static hipError_t run(const GraphDev &g, const ApplyArgs &a, int SL, int grid, hipStream_t st) {
@@ -3581,6 +3756,10 @@ hipError_t HNY_CAT(hnyk_prune_wg_sp, HNY_PART)(const GraphDev &g, const PruneArg
                                                int nw, int grid, hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::PruneWg>(s, g, a, SL, nw, grid, st);
 }
+hipError_t HNY_CAT(hnyk_prune_n8_sp, HNY_PART)(const GraphDev &g, const PruneArgs &a, int lpro, int SL, int grid,
+                                               hipStream_t st) {
+  return Hot<HNY_PART>::prune_n8(g, a, lpro, SL, grid, st);
+}
 hipError_t HNY_CAT(hnyk_apply_sp, HNY_PART)(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,
                                             hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::Apply>(s, g, a, grid, st);
@@ -3632,6 +3811,15 @@ hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int 
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st) {
   if (fast_path(g)) { HNY_SP_SWITCH(hnyk_apply_sp, g, a, s, grid, st) }
   return dispatch_shape<Hot<0>::Apply>(s, g, a, grid, st);
+}
+// the one-wave prune for short rows: plain build, rows of at most 32 units, lists that fit the LDS
+bool hnyk_prune_n8_ok(const GraphDev &g, const PruneArgs &a, LaunchShape s) {
+  const char *e = getenv("HNY_PRUNE_N8"); // read per launch: tests and A/B runs flip it inside one process
+  if (e && atoi(e) == 0) return false;
+  return fast_path(g) && s.nch == 1 && s.lpr <= 32 && !a.list_global && a.rcap <= 512 && a.cap <= (u32)HNY_MAX_CAP;
+}
+hipError_t hnyk_prune_n8(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid, hipStream_t st) {
+  HNY_SP_SWITCH(hnyk_prune_n8_sp, g, a, s.lpr, SL, grid, st)
 }
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st) {

@@ -1101,6 +1101,54 @@ def test_xcd_tiled_walk_queue_equals_oracle(orc, hny, monkeypatch, metric, n, di
     assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
+def test_64_bit_hamming_codes_build_and_search_equal_oracle(orc, hny):
+    """50 000 x 64-bit Hamming codes (65 distinct distances: every walk drags hundreds of ties along): the build
+    — members whose tie pool overflows go through k_walk_heap — equals the oracle's edge for edge, and a search
+    with ef_search = 300, whose pool overflows for most queries, is repeated on the heap-queue searcher
+    (k_nns_filtered without a filter) and returns the restated Reader's ids, distances and counts."""
+    rng = np.random.default_rng(11)
+    n, dim = 50000, 64
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, 3, vecs, draw_levels(n, 16, seed=3))
+    kw = dict(batch_frac=1.0, batch_max=8192)
+    o = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, threads=8, **kw)
+    qs = rng.uniform(-1, 1, (300, dim)).astype(np.float32)
+    qc = orc.encode_vectors(3, qs)
+    qh = orc.make_headers(3, dim, qc)
+    with hny.Builder(items, M=16, M0=32, ef_construction=64, **kw) as b:
+        b.run()
+        g = b.finish()
+        _same_graph(g, o)
+        assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+        for k, ef in ((10, 300), (50, 100)):
+            ids, dists, counts = b.search_knn(qc, qh, k=k, ef_search=ef)
+            oi, od, oc = orc.search(ds, o, qc, qh, k=k, ef_search=ef, order=orc.ORDER_WAVE, threads=8)
+            assert np.array_equal(counts, oc) and np.array_equal(ids, oi) and np.array_equal(dists, od)
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 9000, 128, 16, 32, 100), (3, 9000, 1024, 16, 32, 64),
+                                                  (1, 5000, 60, 12, 24, 40), (4, 4000, 700, 8, 16, 120),
+                                                  (2, 3000, 20, 5, 9, 33), (5, 3000, 2000, 16, 64, 64),
+                                                  (6, 2500, 8, 3, 5, 16)])
+def test_one_wave_prune_for_short_rows_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, ef):
+    """k_prune_n8 (rows <= 512 B: one wave per query, eight candidates per chunk, one per 8-lane group) builds
+    the oracle's graph for every row shape it serves (8 / 16 / 32 lanes in the wave order, f32 and bit codes,
+    odd caps, more selected rows than the LDS stage holds), and so does the workgroup prune it replaces there
+    (HNY_PRUNE_N8=0)."""
+    rng = np.random.default_rng(n + dim)
+    cent = rng.uniform(-1, 1, (12, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 12, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=7))
+    for kw in (dict(batch_frac=1.0, batch_max=4096), dict(batch_frac=0.1, batch_max=128)):
+        o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+        g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+        _same_graph(g, o)
+        assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+    monkeypatch.setenv("HNY_PRUNE_N8", "0")
+    g0 = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g0, o)
+
+
 def _tie_pool_fixture(orc, hny):
     h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
     metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
