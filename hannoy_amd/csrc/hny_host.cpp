@@ -1370,6 +1370,15 @@ static int apply_front(hny_builder *b, const void *sel_dev, ApplyArgs &a) {
   return HNY_OK;
 }
 
+// the targets whose list overflows: one wave each on short rows (k_apply_n8), a 256-thread workgroup otherwise
+static hipError_t launch_apply_deferred(hny_builder *b, const ApplyArgs &a, u32 work) {
+  if (hnyk_apply_n8_ok(b->g, b->shape)) {
+    const int sl = (int)std::min<uint32_t>(HNY_MAX_CAP, std::max<uint32_t>(1, 6144u / b->g.row_stride));
+    return hnyk_apply_n8(b->g, a, b->shape, sl, (int)std::min<u32>(work, 5120u), b->stream);
+  }
+  return hnyk_apply_wg(b->g, a, b->shape, b->stage_rows, (int)std::min<u32>(work, 2048u), b->stream);
+}
+
 static void apply_back(hny_builder *b) {
   b->pos += b->cur.count;
   b->n_done += b->cur.count;
@@ -1385,8 +1394,7 @@ int hny_builder_apply(hny_builder *b, const void *sel_dev) {
   if (int rc = apply_front(b, sel_dev, a)) return rc;
   if (!b->wave_prune_only) {
     prof_begin(b, EV_APPLY);
-    HIP_TRY(hnyk_apply_wg(b->g, a, b->shape, b->stage_rows,
-                          (int)std::min<u32>(std::max<u32>(b->cur_n_ops / 8, 1), 2048), b->stream));
+    HIP_TRY(launch_apply_deferred(b, a, std::max<u32>(b->cur_n_ops / 8, 1)));
     prof_end(b);
   }
   apply_back(b);
@@ -1437,8 +1445,7 @@ int hny_builder_apply_deferred(hny_builder *b, uint32_t rank, uint32_t world, vo
   const u32 per = (b->cur_n_def + world - 1) / world;
   a.exch = world > 1 ? (u64 *)exch_dev + (size_t)rank * per * a.exch_stride : nullptr;
   prof_begin(b, EV_APPLY);
-  HIP_TRY(hnyk_apply_wg(b->g, a, b->shape, b->stage_rows, (int)std::min<u32>(std::max<u32>(per, 1), 2048),
-                        b->stream));
+  HIP_TRY(launch_apply_deferred(b, a, std::max<u32>(per, 1)));
   prof_end(b);
   return HNY_OK;
 }

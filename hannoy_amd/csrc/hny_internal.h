@@ -229,6 +229,9 @@ hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, i
 // robust_prune for rows <= 512 B: one wave per query, 8 candidates at a time (SL = selected rows staged in LDS)
 bool hnyk_prune_n8_ok(const GraphDev &g, const PruneArgs &a, LaunchShape s);
 hipError_t hnyk_prune_n8(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid, hipStream_t st);
+// the deferred add_link targets (k_apply_wg's job) for rows <= 512 B: one wave per target
+bool hnyk_apply_n8_ok(const GraphDev &g, LaunchShape s);
+hipError_t hnyk_apply_n8(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid, hipStream_t st);
 hipError_t hnyk_apply_merge(const GraphDev &g, const u64 *exch, u32 n_def, u32 world, u32 rank, u32 per,
                             u32 stride, hipStream_t st);
 hipError_t hnyk_sort_u32(void *temp, size_t &temp_bytes, u32 *in, u32 *out, u32 n, hipStream_t st);
@@ -259,6 +262,8 @@ size_t hnyk_walk_lds_bytes(u32 rcap, u32 eps_cap);
   hipError_t hnyk_prune_wg_sp##N(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw,      \
                                  int grid, hipStream_t st);                                                 \
   hipError_t hnyk_prune_n8_sp##N(const GraphDev &g, const PruneArgs &a, int lpro, int SL, int grid,         \
+                                 hipStream_t st);                                                           \
+  hipError_t hnyk_apply_n8_sp##N(const GraphDev &g, const ApplyArgs &a, int lpro, int SL, int grid,         \
                                  hipStream_t st);                                                           \
   hipError_t hnyk_apply_sp##N(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,               \
                               hipStream_t st);                                                              \

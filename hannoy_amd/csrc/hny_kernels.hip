@@ -2600,23 +2600,18 @@ __device__ __forceinline__ float dist8(const GraphDev &g, const float4 (&c)[LPRO
 __host__ __device__ inline size_t prune_n8_lds_bytes(u32 rcap, u32 row_stride, int SL) {
   return (size_t)rcap * 8 + (size_t)HNY_MAX_CAP * (8 + 4 + 4) + (size_t)(SL + 1) * row_stride;
 }
+__host__ __device__ inline size_t apply_n8_lds_bytes(u32 row_stride, int SL) {
+  return (size_t)HNY_MAX_CAP * (8 + 8 + 8 + 4 + 4) + (size_t)(SL + 1) * row_stride;
+}
 
-template <int LPRO, int SP>
-__global__ __launch_bounds__(64, 5) void k_prune_n8(GraphDev g_in, PruneArgs a, int SL) {
-  static_assert(LPRO == 8 || LPRO == 16 || LPRO == 32, "rows of at most 32 units, 8 lanes each");
+// the prune of one sorted list by one wave (see above); S / s_ids / s_norm: HNY_MAX_CAP entries, stage: SL rows,
+// newrow: one row.  Returns the number of selected entries, left in S.
+template <int LPRO>
+__device__ __forceinline__ int prune_n8_core(const GraphDev &g, const u64 *list, int n, int cap, u64 *S, u32 *s_ids,
+                                             float *s_norm, unsigned char *stage, unsigned char *newrow, int SL,
+                                             u64 &evals) {
   constexpr int NQ = LPRO / 8;
-  GraphDev g = g_in;
-  specialize<SP>(g);
-  extern __shared__ __align__(16) unsigned char smem[];
-  u64 *list = reinterpret_cast<u64 *>(smem);
-  u64 *S = list + a.rcap;
-  u32 *s_ids = reinterpret_cast<u32 *>(S + HNY_MAX_CAP);
-  float *s_norm = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP);
-  unsigned char *stage = reinterpret_cast<unsigned char *>(s_norm + HNY_MAX_CAP); // [SL] selected rows
-  unsigned char *newrow = stage + (size_t)SL * g.row_stride;                      // the row that has just joined S
   const int ln = HNY_LANE, t = ln & 7, gidx = ln >> 3;
-  const int cap = (int)a.cap;
-  u64 evals = 0;
   auto load8 = [&](const unsigned char *row, float4 (&r)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NQ; k++) {
@@ -2637,86 +2632,189 @@ __global__ __launch_bounds__(64, 5) void k_prune_n8(GraphDev g_in, PruneArgs a, 
       }
     }
   };
+  int s_len = 0;
+  float4 nxt[NQ];
+  float nxt_n = 0.f;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) nxt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (gidx < n) {
+    const u32 c0 = (u32)(list[gidx] & 0xFFFFFFFFull);
+    load8(g.rows + (size_t)c0 * g.row_stride, nxt);
+    if (g.norms) nxt_n = g.norms[c0];
+  }
+  for (int base = 0; base < n && s_len < cap; base += 8) {
+    const int ci = base + gidx;
+    const bool have = ci < n;
+    float4 c[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) c[k] = nxt[k];
+    const float cn = nxt_n;
+    const u64 ck = have ? list[ci] : 0ull;
+    const u32 cid = (u32)(ck & 0xFFFFFFFFull), cdb = (u32)(ck >> 32);
+    if (ci + 8 < n) { // the next chunk's rows travel while this one is scored
+      const u32 nx = (u32)(list[ci + 8] & 0xFFFFFFFFull);
+      load8(g.rows + (size_t)nx * g.row_stride, nxt);
+      if (g.norms) nxt_n = g.norms[nx];
+    }
+    // (2) against S as it stands
+    bool viol = false;
+    for (int j = 0; j < s_len; j++) {
+      const u64 open = __ballot(have && !viol);
+      if (!open) break;
+      float4 r[NQ];
+      if (j < SL) load8_lds(stage + (size_t)j * g.row_stride, r);
+      else load8(g.rows + (size_t)s_ids[j] * g.row_stride, r); // beyond the stage (rare): from L2
+      const float d = dist8<LPRO>(g, c, r, cn, s_norm[j]);
+      viol = viol || fbits(d * g.alpha) < cdb; // hnsw.rs:585
+      evals += (u64)(__popcll(open) >> 3);
+    }
+    // (3) the survivors, in candidate order
+    u64 sv = __ballot(have && !viol && t == 0);
+    while (sv && s_len < cap) {
+      const int l1 = __ffsll((long long)sv) - 1, g1 = l1 >> 3;
+      sv &= sv - 1ull;
+      if (ln == l1) { // :591 S.push(c)
+        S[s_len] = ck;
+        s_ids[s_len] = cid;
+        s_norm[s_len] = cn;
+      }
+      if (gidx == g1) {
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+          const u32 f = (u32)(k * 8 + t);
+          if (f < g.n16) {
+            *reinterpret_cast<float4 *>(newrow + (size_t)f * 16) = c[k];
+            if (s_len < SL) *reinterpret_cast<float4 *>(stage + (size_t)s_len * g.row_stride + (size_t)f * 16) = c[k];
+          }
+        }
+      }
+      WSYNC();
+      if (sv) { // the later survivors against the row that has just joined
+        float4 r[NQ];
+        load8_lds(newrow, r);
+        const float d = dist8<LPRO>(g, c, r, cn, s_norm[s_len]);
+        const bool out = fbits(d * g.alpha) < cdb;
+        evals += (u64)__popcll(sv);
+        sv &= ~__ballot(out && t == 0);
+        WSYNC(); // newrow is rewritten by the next selection
+      }
+      s_len++;
+    }
+  }
+  return s_len;
+}
+
+template <int LPRO, int SP>
+__global__ __launch_bounds__(64, 5) void k_prune_n8(GraphDev g_in, PruneArgs a, int SL) {
+  static_assert(LPRO == 8 || LPRO == 16 || LPRO == 32, "rows of at most 32 units, 8 lanes each");
+  GraphDev g = g_in;
+  specialize<SP>(g);
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *list = reinterpret_cast<u64 *>(smem);
+  u64 *S = list + a.rcap;
+  u32 *s_ids = reinterpret_cast<u32 *>(S + HNY_MAX_CAP);
+  float *s_norm = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP);
+  unsigned char *stage = reinterpret_cast<unsigned char *>(s_norm + HNY_MAX_CAP); // [SL] selected rows
+  unsigned char *newrow = stage + (size_t)SL * g.row_stride;                      // the row that has just joined S
+  const int ln = HNY_LANE;
+  u64 evals = 0;
   for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
     const u32 m = a.perm ? (u32)a.perm[mi - a.lo] : mi; // same locality order as the walk
     const int n = (int)a.cand_n[m];
     for (int e = ln; e < n; e += 64) list[e] = a.cand[(size_t)m * a.rcap + e];
     WSYNC();
-    int s_len = 0;
-    float4 nxt[NQ];
-    float nxt_n = 0.f;
-#pragma unroll
-    for (int k = 0; k < NQ; k++) nxt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gidx < n) {
-      const u32 c0 = (u32)(list[gidx] & 0xFFFFFFFFull);
-      load8(g.rows + (size_t)c0 * g.row_stride, nxt);
-      if (g.norms) nxt_n = g.norms[c0];
-    }
-    for (int base = 0; base < n && s_len < cap; base += 8) {
-      const int ci = base + gidx;
-      const bool have = ci < n;
-      float4 c[NQ];
-#pragma unroll
-      for (int k = 0; k < NQ; k++) c[k] = nxt[k];
-      const float cn = nxt_n;
-      const u64 ck = have ? list[ci] : 0ull;
-      const u32 cid = (u32)(ck & 0xFFFFFFFFull), cdb = (u32)(ck >> 32);
-      if (ci + 8 < n) { // the next chunk's rows travel while this one is scored
-        const u32 nx = (u32)(list[ci + 8] & 0xFFFFFFFFull);
-        load8(g.rows + (size_t)nx * g.row_stride, nxt);
-        if (g.norms) nxt_n = g.norms[nx];
-      }
-      // (2) against S as it stands
-      bool viol = false;
-      for (int j = 0; j < s_len; j++) {
-        const u64 open = __ballot(have && !viol);
-        if (!open) break;
-        float4 r[NQ];
-        if (j < SL) load8_lds(stage + (size_t)j * g.row_stride, r);
-        else load8(g.rows + (size_t)s_ids[j] * g.row_stride, r); // beyond the stage (rare): from L2
-        const float d = dist8<LPRO>(g, c, r, cn, s_norm[j]);
-        viol = viol || fbits(d * g.alpha) < cdb; // hnsw.rs:585
-        evals += (u64)(__popcll(open) >> 3);
-      }
-      // (3) the survivors, in candidate order
-      u64 sv = __ballot(have && !viol && t == 0);
-      while (sv && s_len < cap) {
-        const int l1 = __ffsll((long long)sv) - 1, g1 = l1 >> 3;
-        sv &= sv - 1ull;
-        if (ln == l1) { // :591 S.push(c)
-          S[s_len] = ck;
-          s_ids[s_len] = cid;
-          s_norm[s_len] = cn;
-        }
-        if (gidx == g1) {
-#pragma unroll
-          for (int k = 0; k < NQ; k++) {
-            const u32 f = (u32)(k * 8 + t);
-            if (f < g.n16) {
-              *reinterpret_cast<float4 *>(newrow + (size_t)f * 16) = c[k];
-              if (s_len < SL) *reinterpret_cast<float4 *>(stage + (size_t)s_len * g.row_stride + (size_t)f * 16) = c[k];
-            }
-          }
-        }
-        WSYNC();
-        if (sv) { // the later survivors against the row that has just joined
-          float4 r[NQ];
-          load8_lds(newrow, r);
-          const float d = dist8<LPRO>(g, c, r, cn, s_norm[s_len]);
-          const bool out = fbits(d * g.alpha) < cdb;
-          evals += (u64)__popcll(sv);
-          sv &= ~__ballot(out && t == 0);
-          WSYNC(); // newrow is rewritten by the next selection
-        }
-        s_len++;
-      }
-    }
+    const int s_len = prune_n8_core<LPRO>(g, list, n, (int)a.cap, S, s_ids, s_norm, stage, newrow, SL, evals);
     u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
     if (ln == 0) out[0] = (u64)s_len;
     if (ln < s_len) out[1 + ln] = S[ln];
     WSYNC();
   }
   if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_PRUNE], evals);
+}
+
+// add_link for the targets whose list overflows (hnsw.rs:547-552), short rows: one WAVE per target, the
+// self-prune on prune_n8_core (k_apply_wg: a 256-thread workgroup per target around wg_prune)
+template <int LPRO, int SP>
+__global__ __launch_bounds__(64, 5) void k_apply_n8(GraphDev g_in, ApplyArgs a, int SL) {
+  GraphDev g = g_in;
+  specialize<SP>(g);
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64 *lk = reinterpret_cast<u64 *>(smem); // [HNY_MAX_CAP] the node's list
+  u64 *sorted = lk + HNY_MAX_CAP;          // [HNY_MAX_CAP]
+  u64 *S = sorted + HNY_MAX_CAP;
+  u32 *s_ids = reinterpret_cast<u32 *>(S + HNY_MAX_CAP);
+  float *s_norm = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP);
+  unsigned char *stage = reinterpret_cast<unsigned char *>(s_norm + HNY_MAX_CAP);
+  unsigned char *newrow = stage + (size_t)SL * g.row_stride;
+  const int ln = HNY_LANE;
+  const u32 n_def = *a.n_deferred;
+  u64 evals = 0;
+  const u32 sw = a.shard_world ? a.shard_world : 1u;
+  for (u32 di = a.shard_rank + blockIdx.x * sw; di < n_def; di += gridDim.x * sw) {
+    const u32 i0 = a.deferred[di];
+    const u64 k0 = a.keys[i0] >> HNY_SEQ_BITS;
+    const u32 target = (u32)(k0 & 0x7FFFFFFFull), layer = (u32)(k0 >> 31);
+    u32 cap, *ids, *cntp;
+    float *dist;
+    if (layer == 0) {
+      cap = g.M0;
+      ids = g.l0_ids + (size_t)target * g.M0;
+      dist = g.l0_dist + (size_t)target * g.M0;
+      cntp = g.l0_cnt + target;
+    } else {
+      size_t u = (size_t)g.upper_idx[target] * g.up_layers + (layer - 1);
+      cap = g.M;
+      ids = g.up_ids + u * g.M;
+      dist = g.up_dist + u * g.M;
+      cntp = g.up_cnt + u;
+    }
+    const u32 cw = *cntp;
+    int cnt = (int)(cw & 0xFFFFu);
+    bool frozen = (cw >> 31) != 0u;
+    if (ln < cnt) lk[ln] = ((u64)fbits(dist[ln]) << 32) | ids[ln]; // cap <= 64: one entry per lane
+    WSYNC();
+    for (u32 i = i0; i < a.n_ops && !frozen; i++) {
+      const u64 key = a.keys[i];
+      if (key == HNY_OP_INVALID || (key >> HNY_SEQ_BITS) != k0) break;
+      const u64 val = a.vals[i];
+      if ((u32)(val & 0xFFFFFFFFull) == target) continue; // hnsw.rs:530
+      if (cnt < (int)cap) {                               // :542-545
+        if (ln == 0) lk[cnt] = val;
+        cnt++;
+        WSYNC();
+      } else { // :547-552: the new link is dropped, the full list prunes itself
+        const u64 mine = ln < cnt ? lk[ln] : 0ull;
+        int rk = 0;
+        for (int j = 0; j < cnt; j++) {
+          const u64 o = lk[j];
+          rk += (o < mine || (o == mine && j < ln)) ? 1 : 0;
+        }
+        if (ln < cnt) sorted[rk] = mine;
+        WSYNC();
+        const int s_len = prune_n8_core<LPRO>(g, sorted, cnt, (int)cap, S, s_ids, s_norm, stage, newrow, SL, evals);
+        if (ln < s_len) lk[ln] = S[ln];
+        cnt = s_len;
+        frozen = (s_len == (int)cap); // a full list that prunes to itself can never change again
+        WSYNC();
+      }
+    }
+    if ((u32)ln < cap) {
+      const bool on = ln < cnt;
+      ids[ln] = on ? (u32)(lk[ln] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[ln] = on ? __uint_as_float((u32)(lk[ln] >> 32)) : 0.f;
+    }
+    if (ln == 0) *cntp = (u32)cnt | (frozen ? 0x80000000u : 0u);
+    if (a.exch) { // the finished list, for the ranks that did not compute it
+      u64 *rec = a.exch + (size_t)(di / sw) * a.exch_stride;
+      if (ln == 0) {
+        rec[0] = k0;
+        rec[1] = (u64)((u32)cnt | (frozen ? 0x80000000u : 0u));
+      }
+      if (ln < cnt) rec[2 + ln] = lk[ln];
+    }
+    WSYNC();
+  }
+  if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_APPLY], evals);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3637,6 +3735,18 @@ struct Hot {
       return hipGetLastError();
     }
   }
+  static hipError_t apply_n8(const GraphDev &g, const ApplyArgs &a, int lpro, int SL, int grid, hipStream_t st) {
+    if constexpr (SP == 0) {
+      return hipErrorInvalidValue;
+    } else {
+      const size_t lds = apply_n8_lds_bytes(g.row_stride, SL);
+      if (lpro == 8) hipLaunchKernelGGL((k_apply_n8<8, SP>), dim3(grid), dim3(64), lds, st, g, a, SL);
+      else if (lpro == 16) hipLaunchKernelGGL((k_apply_n8<16, SP>), dim3(grid), dim3(64), lds, st, g, a, SL);
+      else if (lpro == 32) hipLaunchKernelGGL((k_apply_n8<32, SP>), dim3(grid), dim3(64), lds, st, g, a, SL);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    }
+  }
   template <int L, int C>
   struct ApplyWg {
     static hipError_t run(const GraphDev &g, const ApplyArgs &a, int SL, int grid, hipStream_t st) {
@@ -3760,6 +3870,10 @@ hipError_t HNY_CAT(hnyk_prune_n8_sp, HNY_PART)(const GraphDev &g, const PruneArg
                                                hipStream_t st) {
   return Hot<HNY_PART>::prune_n8(g, a, lpro, SL, grid, st);
 }
+hipError_t HNY_CAT(hnyk_apply_n8_sp, HNY_PART)(const GraphDev &g, const ApplyArgs &a, int lpro, int SL, int grid,
+                                               hipStream_t st) {
+  return Hot<HNY_PART>::apply_n8(g, a, lpro, SL, grid, st);
+}
 hipError_t HNY_CAT(hnyk_apply_sp, HNY_PART)(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid,
                                             hipStream_t st) {
   return dispatch_shape<Hot<HNY_PART>::Apply>(s, g, a, grid, st);
@@ -3820,6 +3934,14 @@ bool hnyk_prune_n8_ok(const GraphDev &g, const PruneArgs &a, LaunchShape s) {
 }
 hipError_t hnyk_prune_n8(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int grid, hipStream_t st) {
   HNY_SP_SWITCH(hnyk_prune_n8_sp, g, a, s.lpr, SL, grid, st)
+}
+bool hnyk_apply_n8_ok(const GraphDev &g, LaunchShape s) {
+  const char *e = getenv("HNY_PRUNE_N8");
+  if (e && atoi(e) == 0) return false;
+  return fast_path(g) && s.nch == 1 && s.lpr <= 32 && g.M0 <= (u32)HNY_MAX_CAP && g.M <= (u32)HNY_MAX_CAP;
+}
+hipError_t hnyk_apply_n8(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int SL, int grid, hipStream_t st) {
+  HNY_SP_SWITCH(hnyk_apply_n8_sp, g, a, s.lpr, SL, grid, st)
 }
 hipError_t hnyk_prune_wg(const GraphDev &g, const PruneArgs &a, LaunchShape s, int SL, int nw, int grid,
                          hipStream_t st) {
