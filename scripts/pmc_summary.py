@@ -12,7 +12,8 @@ import sys
 
 
 def family(name):
-    for k in ("k_walk", "k_prune_wg", "k_prune", "k_apply_wg", "k_apply", "k_emit", "k_segments"):
+    for k in ("k_walk_heap", "k_walk", "k_prune_wg", "k_prune_n8", "k_prune", "k_apply_wg", "k_apply_n8", "k_apply_append",
+              "k_apply", "k_emit", "k_segments", "k_finalize_lists"):
         if k in name:
             return k
     return "radix_sort" if "rocprim" in name else "other"

@@ -861,7 +861,9 @@ def test_general_and_specialised_kernels_build_the_same_graph(orc, hny, metric, 
     monkeypatch.setenv("HNY_NO_FAST", "1")
     g0 = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=2048)
     _same_graph(g0, o)
-    assert g0.n_distance_evals == g.n_distance_evals
+    # walk evaluations are determined by the schedule; the prune kernels differ in how many pairs they score
+    # (k_prune_n8 tests eight candidates at a time on short rows, the workgroup prune four)
+    assert g0.n_evals_walk == g.n_evals_walk == o.n_evals_walk
 
 
 def test_locality_ordered_upper_level_batches_equal_oracle(orc, hny):
