@@ -45,10 +45,12 @@ enum {
   HNY_ERR_NO_DEVICE = -6,        /* no usable gfx950 device / HIP failure */
   HNY_ERR_DEVICE = -7,           /* a kernel reported an internal overflow (see hny_last_error): the result
                                   * set of a walk that never evicts outgrew 65 536 entries (4 096 in a
-                                  * filtered search), or more than 128 candidates tied with the result
-                                  * set's maximum at once (tie pool) — inputs the reference still handles,
-                                  * slowly.  Nothing has been written and no graph is returned; there is no
-                                  * CPU path in this library to repeat the call on */
+                                  * filtered search) — an input the reference still handles, slowly.  (More
+                                  * than 128 candidates tying with a result set's maximum — short codes, wide
+                                  * lists — are NOT an error any more: those walks are repeated on heaps in
+                                  * HBM, k_walk_heap / the heap-queue searcher.)  Nothing has been written and
+                                  * no graph is returned; there is no CPU path in this library to repeat the
+                                  * call on */
   HNY_ERR_OOM = -8
 };
 
@@ -124,8 +126,8 @@ typedef struct {
   uint64_t n_evals_walk, n_evals_prune, n_evals_apply;
   uint64_t n_batches;
   double t_upload_s, t_build_s, t_export_s; /* host wall clock of the three phases */
-  uint64_t n_tie_pool_overflow; /* always 0 in a returned graph: an overflow of the walk's tie pool fails
-                                 * the call with HNY_ERR_DEVICE */
+  uint64_t n_tie_pool_overflow; /* always 0 in a returned graph: a walk whose tie pool overflows is repeated
+                                 * on heaps in HBM (k_walk_heap) and is not counted here */
   /* device time per kernel family, from HIP events on the build stream; filled only after
    * hny_builder_set_profiling(b, 1) (else 0) */
   double t_walk_kernels_s, t_prune_kernels_s, t_sort_kernels_s, t_apply_kernels_s;
@@ -246,6 +248,8 @@ int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot
 
 /* ---- search: Reader::nns().by_vector (src/reader.rs:132-148, 642-665, 722-800) on the graph
  * held by the builder (after the build, before destroy).  Queries are codec bytes + headers. */
+/* ef_search (and k) up to 65 535: result sets of up to 4 096 entries live in the walk's LDS, larger ones in
+ * HBM — the reference's own tests search with ef_search = n up to 9 999 (src/tests/reader.rs:82-98) */
 int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvectors, size_t qstride,
                            const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
                            float *out_dists, uint32_t *out_counts);
@@ -261,7 +265,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvect
 #define HNY_NNS_NONE 0xFFFFFFFFu
 typedef struct {
   uint32_t k;                 /* Reader::nns(count) */
-  uint32_t ef_search;         /* default 100 (reader.rs:23) */
+  uint32_t ef_search;         /* default 100 (reader.rs:23); with candidates / by_item: max(ef_search, k) <= 4 095 */
   int32_t has_candidates;     /* .candidates() given (it may be empty) */
   const uint32_t *candidates; /* item ids, any order, duplicates and unknown ids allowed */
   uint64_t n_candidates;

@@ -561,6 +561,28 @@ void robust_prune(Builder &B, std::vector<Link> cands, uint32_t cap, uint64_t &e
       }
     }
     if (ok) selected.push_back(c);
+    else if (std::getenv("ORC_PRUNE_LINK_STATS")) {
+      /* diagnostics (scripts/r3_prune_links.py): could the rejection have been read off STORED links — a
+       * selected s that violates and has c in its layer-0 list (with its distance), or sits in c's list? */
+      static std::atomic<uint64_t> n_rej{0}, via_s{0}, via_c{0}, via_any{0}, n_seen{0};
+      bool fs = false, fc = false;
+      for (const Link &i : selected) {
+        uint64_t dummy = 0;
+        float da = B.d_items(c.id, i.id, dummy) * B.o.alpha;
+        if (!(f32_bits(da) < f32_bits(c.d))) continue;
+        if (NodeList *nl = B.list(0, i.id))
+          for (const Link &l : nl->links) fs = fs || l.id == c.id;
+        if (NodeList *nl = B.list(0, c.id))
+          for (const Link &l : nl->links) fc = fc || l.id == i.id;
+      }
+      n_rej++;
+      via_s += fs;
+      via_c += fc;
+      via_any += (fs || fc);
+      if ((++n_seen & 0xFFFFF) == 0)
+        std::fprintf(stderr, "[prune links] rejected %llu: a violating selected s lists c %.3f, c lists a violating s %.3f, either %.3f\n",
+                     (unsigned long long)n_rej.load(), (double)via_s / n_rej, (double)via_c / n_rej, (double)via_any / n_rej);
+    }
   }
 }
 
