@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SORT_BY_CLUSTER = False  # --sort-by-cluster
 
 
 def parse():
@@ -73,6 +74,9 @@ def parse():
     p.add_argument("--launch-timeout", type=float, default=3000.0,
                    help="self-launched ranks (--gpus N without torchrun) are stopped after this many seconds")
     p.add_argument("--out", default=None, help="also write the JSON line to this file")
+    p.add_argument("--sort-by-cluster", action="store_true",
+                   help="experiment: clustered data with ids in cluster order (neighbours in the graph then have "
+                        "neighbouring ids: what a locality-ordered id space would give the visited bitsets)")
     p.add_argument("--rendezvous-only", action="store_true",
                    help="launch check without a GPU: the ranks meet over gloo and rank 0 reports who came; no build")
     return p.parse_args()
@@ -156,6 +160,8 @@ def gen_data(torch, n, dim, kind, seed, device, queries=False):
     # 1024-centre Gaussian mixture, centres U(-1,1), sigma 0.15: well separated
     centres = torch.rand((1024, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1
     which = torch.randint(0, 1024, (n,), generator=gn, device=device)
+    if SORT_BY_CLUSTER and not queries:
+        which = torch.sort(which).values
     return centres[which] + 0.15 * torch.randn((n, dim), generator=gn, device=device, dtype=torch.float32)
 
 
@@ -188,7 +194,9 @@ def recall_at_k(found, counts, truth):
 
 
 def main():
+    global SORT_BY_CLUSTER
     a = parse()
+    SORT_BY_CLUSTER = a.sort_by_cluster
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and not a.native and "RANK" not in os.environ:
