@@ -43,6 +43,12 @@ int fail(int code, const char *fmt, ...) {
 int hny_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
 // HNY_LEVEL_ORDER=id: items of one level inserted in ascending id order (rounds 1-2) instead of the order
 // Rust's sort_unstable_by leaves them in (hny_rust_sort.h)
+// batches of more than one member: the items of a level group in a fixed pseudo-random order (hny_rust_sort.h);
+// HNY_NO_SHUFFLE=1: consecutive runs of the reference's order (rounds 1-2)
+static bool shuffle_groups(uint32_t batch_max) {
+  const char *e = getenv("HNY_NO_SHUFFLE");
+  return batch_max != 1u && !(e && atoi(e) != 0);
+}
 static bool level_order_by_id() {
   const char *e = getenv("HNY_LEVEL_ORDER");
   return e && (e[0] == 'i' || e[0] == 'I');
@@ -751,6 +757,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
       draw_levels(o.seed, o.M, n, lv.data());
     for (uint32_t s = 0; s < n; s++) levels.push_back({s, lv[s]});
     hny_rust_sort::sort_levels(levels, level_order_by_id()); // hnsw.rs:268, ties as the reference leaves them
+    if (shuffle_groups(b->bmax)) hny_rust_sort::shuffle_level_groups(levels);
     b->max_level = n ? levels[0].second : 0;
     for (uint32_t s = 0; s < n; s++)
       if (lv[s] == b->max_level) b->entry_points.push_back(s);
@@ -805,6 +812,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     for (uint32_t s = 0; s < n; s++)
       if (in_new[s] && !inc->load_only) levels.push_back({s, (uint8_t)max_level}); // :267
     hny_rust_sort::sort_levels(levels, level_order_by_id()); // :268
+    if (shuffle_groups(b->bmax)) hny_rust_sort::shuffle_level_groups(levels);
     if (cur_max > max_level) { // :272-276
       std::fill(in_new.begin(), in_new.end(), 0);
       max_level = cur_max;

@@ -1114,10 +1114,32 @@ struct RustSort {
     quicksort(v, len, nullptr, 2 * lg);
   }
 };
+/* the batch-synchronous schedule (batch_max > 1) takes the items of a level group in a fixed pseudo-random
+ * order, so that a batch is a sample of the group whatever the id order is (the product: hny_rust_sort.h
+ * shuffle_level_groups; any order inside a group is a legitimate parallel execution of hnsw.rs:172-185).
+ * Fisher-Yates on splitmix64, seeded by the group's level and size. */
+uint64_t splitmix64_next(uint64_t &x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+void shuffle_level_groups(std::vector<LevelPair> &v) {
+  size_t b = 0;
+  while (b < v.size()) {
+    size_t e = b;
+    while (e < v.size() && v[e].second == v[b].second) e++;
+    uint64_t st = 0x68616E6E6F79ull ^ ((uint64_t)v[b].second << 48) ^ (uint64_t)(e - b);
+    for (size_t i = e - b; i > 1; i--) std::swap(v[b + i - 1], v[b + (size_t)(splitmix64_next(st) % i)]);
+    b = e;
+  }
+}
 /* orc_opts.level_sort: 0 = ties in ascending id order (stable); 1 = Rust >= 1.81 sort_unstable_by */
-void sort_levels(std::vector<LevelPair> &v, int32_t level_sort) {
+void sort_levels(std::vector<LevelPair> &v, int32_t level_sort, const orc_opts *o) {
   if (level_sort == 1) RustSort::sort(v);
   else std::stable_sort(v.begin(), v.end(), [](const LevelPair &a, const LevelPair &b) { return a.second > b.second; });
+  if (o->batch_max > 1 && !o->no_shuffle) shuffle_level_groups(v);
 }
 } // namespace
 
@@ -1154,7 +1176,7 @@ int orc_build(const orc_opts *opts, const orc_items *items, orc_graph **out) {
   {
     std::vector<LevelPair> lv(n);
     for (uint32_t s = 0; s < n; s++) lv[s] = {s, B.level[s]};
-    sort_levels(lv, opts->level_sort);
+    sort_levels(lv, opts->level_sort, opts);
     for (uint32_t s = 0; s < n; s++) order[s] = lv[s].first;
   }
 
@@ -1329,7 +1351,7 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
   if (!del_eps.empty() && n_new != n_old) max_level = 0; /* :261-263 */
   for (uint32_t s = 0; s < n; s++)
     if (in_new[s]) levels.push_back({s, max_level}); /* :267 re-index the old entry points */
-  sort_levels(levels, opts->level_sort); /* :268 (unstable in Rust; stable == what inputs of <= 20 pairs get) */
+  sort_levels(levels, opts->level_sort, opts); /* :268 (unstable in Rust; stable == what inputs of <= 20 pairs get) */
   if (cur_max_level > max_level) { /* :272-276 */
     std::fill(in_new.begin(), in_new.end(), 0);
     max_level = cur_max_level;

@@ -68,6 +68,9 @@ typedef struct {
    * 1 = Rust >= 1.81's sort_unstable_by (ipnsort) restated — pinned by KAT-9, the reference's
    *     100-point snapshots (src/tests/writer.rs:130-155), which only this order reproduces. */
   int32_t level_sort;
+  /* batch_max > 1: the items of a level group are taken in a fixed pseudo-random order (see
+   * hannoy_oracle.cpp shuffle_level_groups); 1 = consecutive runs of the sorted order instead (rounds 1-2) */
+  int32_t no_shuffle;
 } orc_opts;
 
 typedef struct {

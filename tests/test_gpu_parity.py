@@ -1170,6 +1170,45 @@ def test_tiny_rows_build_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M,
         assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
+def test_ids_sorted_by_cluster_do_not_break_the_index(orc, hny, monkeypatch):
+    """Batch-synchronous insertion and ids that are sorted by cluster (documents grouped by topic): a batch of
+    consecutive ids is a few whole clusters none of whose points are in the graph yet — every member searches
+    a graph that does not contain its neighbourhood, and recall collapses (round 3 measured 0.42 instead of
+    0.95 at C2).  The schedule therefore takes the items of a level group in a fixed pseudo-random order
+    (hny_rust_sort.h shuffle_level_groups, restated in the oracle): recall on sorted ids equals recall on
+    shuffled ids, the graph equals the oracle's; HNY_NO_SHUFFLE=1 shows what it guards against."""
+    rng = np.random.default_rng(8)
+    n, dim, ncl, nq = 30000, 48, 30, 300
+    cent = rng.uniform(-1, 1, (ncl, dim)).astype(np.float32)
+    which = np.sort(rng.integers(0, ncl, n))            # ids in cluster order
+    vecs = (cent[which] + 0.15 * rng.standard_normal((n, dim))).astype(np.float32)
+    qs = (cent[rng.integers(0, ncl, nq)] + 0.15 * rng.standard_normal((nq, dim))).astype(np.float32)
+    d2 = ((qs ** 2).sum(1)[:, None] - 2 * qs @ vecs.T + (vecs ** 2).sum(1)[None, :])
+    truth = np.argsort(d2, axis=1)[:, :10]
+    levels = draw_levels(n, 16, seed=1)
+    ds, items = _mk(orc, hny, 1, vecs, levels)
+    qc = orc.encode_vectors(1, qs)
+    qh = orc.make_headers(1, dim, qc)
+    kw = dict(M=16, M0=32, ef_construction=64, batch_frac=1.0, batch_max=8192)
+
+    def recall():
+        with hny.Builder(items, **kw) as b:
+            b.run()
+            g = b.finish()
+            ids, _, cnt = b.search_knn(qc, qh, k=10, ef_search=64)
+        hit = sum(len(set(ids[i, :cnt[i]].tolist()) & set(truth[i].tolist())) for i in range(nq))
+        return g, hit / truth.size
+    g, r_shuffled = recall()
+    o = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, threads=8, batch_frac=1.0, batch_max=8192)
+    _same_graph(g, o)
+    monkeypatch.setenv("HNY_NO_SHUFFLE", "1")
+    g1, r_runs = recall()
+    o1 = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, threads=8, batch_frac=1.0, batch_max=8192)
+    _same_graph(g1, o1)
+    assert r_shuffled > 0.9, r_shuffled
+    assert r_runs < r_shuffled - 0.1, (r_runs, r_shuffled)  # consecutive runs of sorted ids: a visibly worse index
+
+
 def _tie_pool_fixture(orc, hny):
     h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
     metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
