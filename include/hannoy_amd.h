@@ -79,9 +79,11 @@ typedef struct {
   void (*progress)(void *, uint64_t done, uint64_t total); /* progress.rs:3-16 */
   void *progress_ctx;
   /* batch-synchronous insertion schedule: batch = clamp(floor(batch_frac * n_inserted), 1,
-   * batch_max).  batch_max = 1 reproduces strictly sequential insertion (the reference with one
-   * rayon thread, src/tests/mod.rs:105).  0 / 0.0 select the defaults: batch_frac 1.0,
-   * batch_max hny_default_batch_max(n). */
+   * batch_max).  batch_max = 1 reproduces strictly sequential insertion in the reference's own order
+   * (hnsw.rs:268 incl. the order Rust's sort_unstable_by leaves equal levels in — the reference with
+   * one rayon thread, src/tests/mod.rs:105).  With batch_max != 1 the items of a level group are taken
+   * in a fixed pseudo-random order, so that a batch is a sample of the group whatever the id order
+   * (DESIGN.md §1).  0 / 0.0 select the defaults: batch_frac 1.0, batch_max hny_default_batch_max(n). */
   double batch_frac;
   uint32_t batch_max;
   int32_t device;            /* HIP device ordinal; -1 = current */
