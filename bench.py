@@ -477,14 +477,15 @@ def main():
                        f"full one, so this flatters the CPU; --cpu-full times all of them)") +
                       f", same params, vectors in RAM, {cores} threads (rayon-like), AVX2+FMA kernels",
             "seconds": round(tc, 2)}
-        full = os.path.join(ROOT, "profiles", "r01_c2_full_scale_recall_parity_final.json")
+        full = os.path.join(ROOT, "profiles", "r03_c2_full_scale_recall_parity.json")
         if default_c2 and ns != a.n and os.path.exists(full):  # one-off measurement of the same baseline at full size
             with open(full) as f:
                 fj = json.load(f)
             out["cpu_baseline"]["full_size_run"] = {
-                "vectors_per_s": round(fj["cpu_vec_per_s"], 1), "seconds": round(fj["cpu_build_s"], 1),
-                "cores": fj["cores"], "recall_at_10": fj["recall_cpu_built_cpu_search"],
-                "source": "profiles/r01_c2_full_scale_recall_parity_final.json (scripts/recall_parity_full.py)"}
+                "vectors_per_s": fj["cpu_vec_per_s"], "seconds": fj["cpu_build_s"], "cores": fj["cores"],
+                "recall_at_10_cpu_built": fj["recall_at_10"]["100"]["cpu_built"],
+                "recall_at_10_gpu_built": fj["recall_at_10"]["100"]["gpu_built"],
+                "source": "profiles/r03_c2_full_scale_recall_parity.json (scripts/recall_parity_full.py --config C2)"}
         # recall parity on the sample: CPU-built vs GPU-built graph, both searched by the oracle
         if not a.no_recall and a.queries:
             sub = H.ItemSet(metric, a.dim, ds.ids, ds.codes, ds.headers, lv)
