@@ -827,8 +827,14 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
         b->entry_points.push_back(s);
         if (!has_vec[s]) return fail(HNY_ERR_MISSING_KEY, "entry point %u has no item", U[s]);
       }
-    for (uint32_t s = 0; s < n; s++) // schedule: surviving old layer-0 records count as inserted
-      if ((b->old_mask[s] & 1) && !b->deleted[s]) b->n_done0++;
+    // The batch schedule of an update ramps up from one member like a fresh build's (n_done0 stays 0): rounds
+    // 1-2 counted the surviving old records as "already inserted", so an update went in as one or two batches —
+    // and new items that form a region of their own (a new topic appended to an index) searched a graph that
+    // held none of them: measured recall 0.51 on such a region against 0.99 with the ramp
+    // (scripts/r3_new_region_update.py).  HNY_UPDATE_NO_RAMP=1: the old rule.
+    if (env_int("HNY_UPDATE_NO_RAMP", 0) != 0)
+      for (uint32_t s = 0; s < n; s++)
+        if ((b->old_mask[s] & 1) && !b->deleted[s]) b->n_done0++;
     for (uint32_t s = 0; s < n; s++)
       for (uint32_t ll = 0; ll <= HNY_MAX_LEVEL; ll++)
         if (((b->old_mask[s] >> ll) & 1) && !b->deleted[s]) b->old_recs.push_back(((u64)ll << 31) | s);

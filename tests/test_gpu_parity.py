@@ -1209,6 +1209,51 @@ def test_ids_sorted_by_cluster_do_not_break_the_index(orc, hny, monkeypatch):
     assert r_runs < r_shuffled - 0.1, (r_runs, r_shuffled)  # consecutive runs of sorted ids: a visibly worse index
 
 
+def test_update_that_adds_a_new_region(orc, hny, monkeypatch):
+    """An update whose new items form regions of their own (a new topic appended to an index).  Rounds 1-2
+    counted the surviving old records as "already inserted", so the 12 000 new items went in as one batch whose
+    members cannot see each other: recall 0.51 on the new region.  An update's batches now ramp up from one
+    member like a fresh build's: recall on the new region is what a fresh build of everything gives, and the
+    graph equals the oracle's under the same rule; HNY_UPDATE_NO_RAMP=1 shows what it guards against."""
+    rng = np.random.default_rng(5)
+    dim, nA, nB, nq = 48, 30000, 12000, 300
+    centA = rng.uniform(-1, 1, (30, dim)).astype(np.float32)
+    centB = rng.uniform(-1, 1, (12, dim)).astype(np.float32)
+    A = (centA[rng.integers(0, 30, nA)] + 0.15 * rng.standard_normal((nA, dim))).astype(np.float32)
+    B = (centB[rng.integers(0, 12, nB)] + 0.15 * rng.standard_normal((nB, dim))).astype(np.float32)
+    qs = (centB[rng.integers(0, 12, nq)] + 0.15 * rng.standard_normal((nq, dim))).astype(np.float32)
+    allv = np.concatenate([A, B])
+    d2 = ((qs ** 2).sum(1)[:, None] - 2 * qs @ allv.T + (allv ** 2).sum(1)[None, :])
+    truth = np.argsort(d2, axis=1)[:, :10]
+    kw = dict(M=16, M0=32, ef_construction=64)
+    kwo = dict(M=16, M0=32, ef=64, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=65536, threads=8)
+    dsA, itA = _mk(orc, hny, 1, A, draw_levels(nA, 16, seed=1))
+    gA = hny.build(itA, **kw)
+    oA = orc.build(dsA, **kwo)
+    _same_graph(gA, oA)
+    lvB = draw_levels(nB, 16, seed=2)
+    dsAll = orc.Dataset.from_f32(1, allv, np.zeros(nA + nB, np.uint8))
+    itAll = hny.ItemSet(1, dim, dsAll.ids, dsAll.codes, dsAll.headers, lvB)
+    ins = np.arange(nA, nA + nB, dtype=np.uint32)
+    qc = orc.encode_vectors(1, qs)
+    qh = orc.make_headers(1, dim, qc)
+
+    def recall(g):
+        with hny.Builder(itAll, prev=g, load=True, **kw) as b:
+            ids, _, cnt = b.search_knn(qc, qh, k=10, ef_search=64)
+        return sum(len(set(ids[i, :cnt[i]].tolist()) & set(truth[i].tolist())) for i in range(nq)) / truth.size
+    g2 = hny.build_incremental(itAll, gA, ins, [], **kw)
+    o2 = orc.build_incremental(dsAll, oA, ins, lvB, [], **kwo)
+    _same_graph(g2, o2)
+    assert g2.n_batches > 10
+    r = recall(g2)
+    assert r > 0.93, r
+    monkeypatch.setenv("HNY_UPDATE_NO_RAMP", "1")
+    g3 = hny.build_incremental(itAll, gA, ins, [], **kw)
+    _same_graph(g3, orc.build_incremental(dsAll, oA, ins, lvB, [], **kwo))
+    assert g3.n_batches <= 5 and recall(g3) < r - 0.2
+
+
 def _tie_pool_fixture(orc, hny):
     h = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_pool_overflow_hamming3_m0_333.npz"))
     metric, dim, M, M0, ef, bmax = [int(x) for x in h["params"]]
