@@ -3,7 +3,7 @@
 
 The regular -m gpu suite checks the full-size builds through size-independent properties (the oracle
 needs minutes per config on the box's host cores); this script does the whole comparison once per
-round and writes profiles/r02_full_size_graph_parity.json:  same data as bench.py, same levels, same
+round and writes gpurun_out/r03_full_size_graph_parity.json (-> profiles/):  same data as bench.py, same levels, same
 batch schedule, oracle in the wave summation order on every host core -> identical records
 (rec_item, rec_layer, offsets, neighbours), entry points, link count and walk-evaluation count.
 
@@ -44,7 +44,9 @@ def main():
     heartbeat()
     dev = torch.device("cuda", 0)
     cores = os.cpu_count() or 1
-    out_path = os.path.join(ROOT, "profiles", "r02_full_size_graph_parity.json")
+    # (on the GPU box only gpurun_out/ travels back: copy the file to profiles/ afterwards)
+    out_path = os.environ.get("OUT", os.path.join(ROOT, "gpurun_out", "r03_full_size_graph_parity.json"))
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     for name in which:
         mname, n, dim, M, ef = CFG[name]
