@@ -7,7 +7,7 @@ round and writes gpurun_out/r03_full_size_graph_parity.json (-> profiles/):  sam
 batch schedule, oracle in the wave summation order on every host core -> identical records
 (rec_item, rec_layer, offsets, neighbours), entry points, link count and walk-evaluation count.
 
-  python scripts/full_size_graph_parity.py [C2 C3 C5 C4]
+  python scripts/full_size_graph_parity.py [C2 C3 C5 C4_4M C4]
 """
 import json
 import os
@@ -25,7 +25,9 @@ from bench import gen_data  # noqa: E402
 from oracle import orc  # noqa: E402
 
 CFG = {"C2": ("cosine", 1_000_000, 768, 16, 100), "C3": ("euclidean", 1_000_000, 768, 32, 200),
-       "C4": ("cosine", 10_000_000, 128, 16, 100), "C5": ("hamming", 5_000_000, 1024, 16, 64)}
+       "C4": ("cosine", 10_000_000, 128, 16, 100), "C5": ("hamming", 5_000_000, 1024, 16, 64),
+       # C4's shape at 40 % of its size: what the oracle finishes inside one gpurun call (C4 itself: > 30 min)
+       "C4_4M": ("cosine", 4_000_000, 128, 16, 100)}
 
 
 def heartbeat():
