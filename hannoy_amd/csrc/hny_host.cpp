@@ -2048,7 +2048,8 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.eps_cap = eps_cap_of(b);
     w.queue = queues;
     w.cancel = sc.d;
-    w.pool_flag = (ef + 1 <= HNY_RES_LDS_MAX && env_int("HNY_NO_POOL_RETRY", 0) == 0) ? 1u : 0u;
+    w.pool_flag = env_int("HNY_NO_POOL_RETRY", 0) == 0 ? 1u : 0u;
+    w.force_pool = (u32)std::max(0, env_int("HNY_POOL_FORCE_RETRY", 0)); // tests: every k-th query takes the retry path
     if (sc.d) HIP_TRY(hnyk_fill_u32(dcn.p, 0xFFFFFFFFu, cnt, b->stream)); // = never finished
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     const int grid = (int)std::min<uint32_t>(cnt, b->walk_slots);
@@ -2101,7 +2102,60 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
       }
       out_counts[q0 + i] = c;
     }
-    if (!again.empty() && !sc.cancelled) {
+    if (!again.empty() && !sc.cancelled && ef + 1 > HNY_RES_LDS_MAX) {
+      // result sets beyond the LDS: the same queries once more with `candidates` AND `res` as heaps in HBM
+      // (k_walk_heap in reader mode: the build's own safety net), on the chunk's buffers
+      const u32 na = (u32)again.size();
+      DevBuf<u32> dlist; // [0] = count, [1] = work counter, then the members
+      DevBuf<u64> dheap_r;
+      HIP_TRY(dlist.alloc((size_t)na + 2));
+      std::vector<u32> hl((size_t)na + 2);
+      hl[0] = na;
+      hl[1] = 0u;
+      std::copy(again.begin(), again.end(), hl.begin() + 2);
+      HIP_TRY(hipMemcpyAsync(dlist.p, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, b->stream));
+      const u32 hgrid = (u32)std::max<uint64_t>(
+          1, std::min<uint64_t>(std::min<u32>(na, b->heap_grid), ((uint64_t)1 << 30) / (((uint64_t)rcap + 1) * 8)));
+      HIP_TRY(dheap_r.alloc((size_t)hgrid * ((size_t)rcap + 1)));
+      WalkArgs h = w;
+      h.first = 1;
+      h.eps_in = nullptr;
+      h.perm = nullptr;
+      h.xcd_tile = 0;
+      h.descend_only = 0;
+      h.pool_flag = 0;
+      h.pool_retry = dlist.p + 2;
+      h.n_pool_retry = dlist.p;
+      h.queue = dlist.p + 1;
+      h.heap_c = b->d_heap_c.p;
+      h.heap_c_cap = b->heap_c_cap;
+      h.heap_r = dheap_r.p;
+      h.heap_r_cap = rcap + 1;
+      if (sc.d) { // "never finished" for the members a cancellation leaves out
+        for (u32 i : again) hn[i] = 0xFFFFFFFFu;
+        HIP_TRY(hipMemcpyAsync(dcn.p, hn.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, b->stream));
+      }
+      b->n_walk_dispatch++;
+      HIP_TRY(hnyk_walk_heap(b->g, h, b->shape, (int)hgrid, b->stream));
+      HIP_TRY(hnyk_take_topk(dcand.p, dcn.p, rcap, k, cnt, dtop.p, b->stream));
+      HIP_TRY(hipMemcpyAsync(hc.data(), dtop.p, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, b->stream));
+      HIP_TRY(hipMemcpyAsync(hn.data(), dcn.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, b->stream));
+      HIP_TRY(sc.wait(b));
+      for (uint32_t i : again) {
+        if (hn[i] >= 0xFFFFFFFEu) { // cancelled before it ran (or failed: the error words say so below)
+          out_counts[q0 + i] = 0u;
+          continue;
+        }
+        const uint32_t c = std::min<uint32_t>(k, hn[i]);
+        for (uint32_t j = 0; j < c; j++) {
+          const u64 e = hc[(size_t)i * k + j];
+          out_ids[(q0 + i) * k + j] = b->ids[(uint32_t)(e & 0xFFFFFFFFull)];
+          const uint32_t db = (uint32_t)(e >> 32);
+          memcpy(&out_dists[(q0 + i) * k + j], &db, 4);
+        }
+        out_counts[q0 + i] = c;
+      }
+    } else if (!again.empty() && !sc.cancelled) {
       // the same queries on the searcher whose queue is a real heap in HBM: nothing to overflow, same results
       const size_t na = again.size();
       std::vector<unsigned char> av(na * vb), ah(na * hb);

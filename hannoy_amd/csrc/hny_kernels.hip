@@ -82,6 +82,7 @@ __device__ __forceinline__ void specialize(GraphDev &g) {
 // wave-uniform values that were read from LDS or produced by a cross-lane reduction sit in VGPRs;
 // readfirstlane moves them to SGPRs (lower VGPR pressure, scalar branches)
 __device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ u64 uni64(u64 x) { return ((u64)uni((u32)(x >> 32)) << 32) | (u64)uni((u32)x); }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ u64 uni(u64 x) {
   return ((u64)uni((u32)(x >> 32)) << 32) | (u64)uni((u32)(x & 0xFFFFFFFFull));
@@ -1579,7 +1580,8 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     if constexpr (RM || SP == 0) {
       // a search whose tie pool overflowed: flagged instead of counted, the host repeats the query on the
       // heap-queue searcher (k_nns_filtered without a filter), which has no pool
-      if (a.reader_mode && a.pool_flag && s.pool_over) {
+      // (force_pool: tests send every k-th query that way)
+      if (a.reader_mode && a.pool_flag && (s.pool_over || (a.force_pool && m % a.force_pool == 0u))) {
         total = (int)0xFFFFFFFEu;
         s.pool_over = 0;
       }
@@ -2049,7 +2051,9 @@ __device__ int walk_layer_heap(const GraphDev &g, const float4 (&q)[NCH], float 
   return 0;
 }
 
-// k_walk's member loop for the members of a.pool_retry (build walks only), every walk_layer call on heaps
+// k_walk's member loop for the members of a.pool_retry, every walk_layer call on heaps: build walks whose
+// tie pool overflowed, and (a.reader_mode) the Reader's searches in the same situation whose result set is
+// too long for k_nns_filtered's LDS (ef_search >= 4 096: hny_builder_search_knn)
 template <int LPR, int NCH>
 __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2071,13 +2075,24 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
   u32 err = 0, log_over_cnt = 0;
   for (;;) {
     u32 mi = 0;
-    if (ln == 0) mi = atomicAdd(a.queue, 1u);
+    if (ln == 0) {
+      mi = atomicAdd(a.queue, 1u);
+      // the Visitor's cancel probe (reader.rs:333), between queries (searches only: builds pass no flag)
+      if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) mi = 0xFFFFFFFFu;
+    }
     mi = uni(mi);
     if (mi >= n_mem) break;
     const u32 m = uni(a.pool_retry[mi]);
-    const u32 qslot = a.q_slots[m];
-    const unsigned char *qrow = g.rows + (size_t)qslot * g.row_stride;
-    const float qn = g.norms ? g.norms[qslot] : 0.f;
+    const unsigned char *qrow;
+    float qn = 0.f;
+    if (a.q_rows) { // a search: the query is not an item
+      qrow = a.q_rows + (size_t)m * a.q_stride;
+      if (a.q_norms) qn = a.q_norms[m];
+    } else {
+      const u32 qslot = a.q_slots[m];
+      qrow = g.rows + (size_t)qslot * g.row_stride;
+      if (g.norms) qn = g.norms[qslot];
+    }
     float4 q[NCH];
     load_row<LPR, NCH>(qrow, t, g.n16, q);
     int n_eps;
@@ -2110,8 +2125,12 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
       if (ln == 0) eps[0] = closest;
       n_eps = 1;
       lkey = (lkey << 16) | (u64)((u32)g.upper_idx[closest] & 0xFFFFu);
-      if (vis.log_over) log_over_cnt++;
-      visited_clear(vis); // walk_layer owns a fresh visited set
+      // walk_layer owns a fresh visited set; Reader::hnsw_search shares `path` across the greedy layers and
+      // clears it once before layer 0 (reader.rs:731-743)
+      if (!a.reader_mode || layer == a.layer + 1) {
+        if (vis.log_over) log_over_cnt++;
+        visited_clear(vis);
+      }
       WSYNC();
     }
     if (!st && a.descend_only) {
@@ -2121,16 +2140,72 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
       }
     } else if (!st) {
       // res.into_vec(), ascending: pop the maxima into the row from its end
-      const u32 total = R.size;
+      u32 total = R.size;
+      u64 *row = a.cand + (size_t)m * a.rcap;
+      auto drain = [&](u32 at) { // R, ascending, into row[at ..)
+        for (u32 i = R.size; i-- > 0u;) {
+          const u64 key = ~R.top;
+          if (ln == 0) row[at + i] = key;
+          qheap_pop(R);
+        }
+      };
       if (total > a.rcap) {
         st = 1;
       } else {
-        for (u32 i = total; i-- > 0u;) {
-          const u64 key = ~R.top;
-          if (ln == 0) a.cand[(size_t)m * a.rcap + i] = key;
-          qheap_pop(R);
+        drain(0u);
+        if (a.reader_mode && total < a.knn_k) {
+          // Reader::hnsw_search's exhaustive fallback (reader.rs:771-795), as in k_walk: restart from every
+          // item not seen yet, ascending, sharing the visited set, until opt.ef hits are collected
+          const u32 nwords = (g.n + 31) >> 5;
+          u32 pos = 0;
+          visited_flush(vis);
+          while (pos < g.n && !st) {
+            const u32 wbase = pos >> 5;
+            const u32 widx = wbase + (u32)ln;
+            u32 unv = 0u;
+            if (widx < nwords) {
+              unv = ~__hip_atomic_load(&vis.bits[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
+              if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
+            }
+            const u64 mk = __ballot(unv != 0u);
+            if (!mk) {
+              pos = (wbase + 64u) << 5;
+              continue;
+            }
+            const int l0 = __ffsll((long long)mk) - 1;
+            const u32 w0 = (u32)__builtin_amdgcn_readlane((int)unv, l0);
+            const u32 slot = ((wbase + (u32)l0) << 5) + (u32)__builtin_ctz(w0);
+            pos = slot + 1;
+            if (g.incremental && !g.has_vec[slot]) continue;
+            const int ef2 = a.knn_ef > total ? (int)(a.knn_ef - total) : 0; // saturating_sub :786
+            WSYNC();
+            if (ln == 0) eps[0] = slot;
+            WSYNC();
+            st = walk_layer_heap<LPR, NCH>(g, q, qn, 0u, ef2, eps, 1, C, R, rmin, vis, nb_ids, nb_d, evals, qrow);
+            if (st) break;
+            if (total + R.size > a.rcap) {
+              st = 1;
+              break;
+            }
+            const u32 got = R.size;
+            drain(total); // neighbours.extend(more_nns)
+            total += got;
+            if (total >= a.knn_ef) break; // :792-794
+          }
+          if (!st) { // drain_asc(): everything that was collected, sorted — through the heap once more
+            __threadfence_block();
+            WSYNC();
+            R.size = 0;
+            R.top = ~0ull;
+            for (u32 i = 0; i < total && !st; i++) {
+              const u64 key = uni64(row[i]);
+              if (!qheap_push(R, ~key)) st = 1;
+            }
+            if (!st) drain(0u);
+          }
         }
-        if (ln == 0) a.cand_n[m] = total;
+        if (!st && ln == 0) a.cand_n[m] = total;
       }
     }
     if (st) err = 1;

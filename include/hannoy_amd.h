@@ -251,7 +251,9 @@ int hny_builder_distances(hny_builder *b, uint64_t n_pairs, const uint32_t *slot
 /* ---- search: Reader::nns().by_vector (src/reader.rs:132-148, 642-665, 722-800) on the graph
  * held by the builder (after the build, before destroy).  Queries are codec bytes + headers. */
 /* ef_search (and k) up to 65 535: result sets of up to 4 096 entries live in the walk's LDS, larger ones in
- * HBM — the reference's own tests search with ef_search = n up to 9 999 (src/tests/reader.rs:82-98) */
+ * HBM — the reference's own tests search with ef_search = n up to 9 999 (src/tests/reader.rs:82-98).  A query
+ * whose walk overflows its tie pool (short codes: a handful of distinct distances) is searched again on heaps
+ * in HBM and returns the same hits: no input fails for it. */
 int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvectors, size_t qstride,
                            const void *qheaders, uint32_t k, uint32_t ef_search, uint32_t *out_ids,
                            float *out_dists, uint32_t *out_counts);

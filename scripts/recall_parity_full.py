@@ -9,7 +9,7 @@ StdRng::seed_from_u64(42) -> ChaCha12 -> WeightedIndex), GPU build with the DEFA
 hny_default_batch_max), CPU build = the oracle in rayon-like mode on every host core in the reference's x86
 summation order.  Both graphs are searched by the same searcher (hny_builder_search_knn == the restated
 Reader, bit for bit: tests/test_gpu_nns.py) for 1 000 held-out queries against exact ground truth, at
-ef_search = 100 and at the first ef_search of 200 / 400 / 800 / 1600 where the CPU-built index reaches 0.9
+ef_search = 100 and at the first ef_search of 200 / 400 / 800 / 1600 (--deep: … 12 800) where the CPU-built index reaches 0.9
 (dense synthetic clusters sit well below that at 100).  Prints / writes one JSON object."""
 import argparse
 import json
@@ -40,6 +40,7 @@ def main():
     p.add_argument("--batch-max", type=int, default=0)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--out", default=None)
+    p.add_argument("--deep", action="store_true", help="also ef_search 3 200 / 6 400 / 12 800 (dense synthetic clusters)")
     a = p.parse_args()
     c = dict(CONFIGS[a.config])
     if a.items:
@@ -73,7 +74,7 @@ def main():
     cores = os.cpu_count() or 1
     out = {"config": a.config, **c, "M0": M0, "data": a.data, "queries": a.queries, "cores": cores,
            "batch_max": a.batch_max or H.default_batch_max(c["n"]), "levels": "StdRng::seed_from_u64(%d)" % a.seed}
-    efs = [100, 200, 400, 800, 1600]
+    efs = [100, 200, 400, 800, 1600] + ([3200, 6400, 12800] if a.deep else [])
 
     def recalls(builder):
         r = {}

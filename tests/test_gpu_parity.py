@@ -1128,6 +1128,55 @@ def test_64_bit_hamming_codes_build_and_search_equal_oracle(orc, hny):
             assert np.array_equal(counts, oc) and np.array_equal(ids, oi) and np.array_equal(dists, od)
 
 
+def test_search_with_result_sets_beyond_the_lds_survives_a_tie_pool_overflow(orc, hny, monkeypatch):
+    """ef_search >= 4 096 keeps the result set in HBM; on 64-bit Hamming codes the walk's tie pool overflows for
+    such a search (found at C5 with ef_search = 6 400: the call failed with "tie pool overflow").  Those queries
+    are walked again by k_walk_heap in reader mode (`candidates` and `res` as heaps in HBM) and return the
+    restated Reader's ids, distances and counts.  Second half: the same path forced for EVERY query
+    (HNY_POOL_FORCE_RETRY=1) on an index with zero vectors and ef_search > n, where the Reader's exhaustive
+    fallback (reader.rs:771-795) runs inside the heap kernel, and with ef_search = 300 through the LDS searcher."""
+    rng = np.random.default_rng(21)
+    n, dim = 12000, 64
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, 3, vecs, draw_levels(n, 16, seed=4))
+    qs = rng.uniform(-1, 1, (48, dim)).astype(np.float32)
+    qc = orc.encode_vectors(3, qs)
+    qh = orc.make_headers(3, dim, qc)
+    kw = dict(batch_frac=1.0, batch_max=4096)
+    with hny.Builder(items, M=16, M0=32, ef_construction=48, **kw) as b:
+        b.run()
+        g = b.finish()
+        got = b.search_knn(qc, qh, k=10, ef_search=5000)
+        monkeypatch.setenv("HNY_NO_POOL_RETRY", "1")  # without the safety net the same search fails loudly
+        with pytest.raises(hny.HannoyError) as e:
+            b.search_knn(qc, qh, k=10, ef_search=5000)
+        assert e.value.code == -7 and "tie pool overflow" in str(e.value)
+        monkeypatch.delenv("HNY_NO_POOL_RETRY")
+    want = orc.search(ds, g, qc, qh, k=10, ef_search=5000, order=orc.ORDER_WAVE, threads=8)
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+    monkeypatch.setenv("HNY_POOL_FORCE_RETRY", "1")
+    n, dim, M, M0, ef = 3000, 64, 8, 16, 64
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    vecs[rng.integers(0, n, 40)] = 0.0  # zero vectors: distance 0 to everything -> ties, trapped walks
+    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, M, seed=3))
+    qs = rng.uniform(-1, 1, (100, dim)).astype(np.float32)
+    qs[:5] = 0.0
+    qc = orc.encode_vectors(0, qs)
+    qh = orc.make_headers(0, dim, qc)
+    with hny.Builder(items, M=M, M0=M0, ef_construction=ef, batch_frac=0.2, batch_max=256) as b:
+        b.run()
+        g = b.finish()
+        for k, ef_s in ((10, 4500), (10, 300), (3500, 10)):
+            got = b.search_knn(qc, qh, k=k, ef_search=ef_s)
+            want = orc.search(ds, g, qc, qh, k=k, ef_search=ef_s, order=orc.ORDER_WAVE, threads=8)
+            assert np.array_equal(got[2], want[2]), (k, ef_s)
+            for r in range(len(want[2])):
+                c = int(want[2][r])
+                assert np.array_equal(got[0][r, :c], want[0][r, :c]), (k, ef_s, r)
+                assert np.array_equal(got[1][r, :c].view(np.uint32), want[1][r, :c].view(np.uint32)), (k, ef_s, r)
+
+
 @pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(0, 9000, 128, 16, 32, 100), (3, 9000, 1024, 16, 32, 64),
                                                   (1, 5000, 60, 12, 24, 40), (4, 4000, 700, 8, 16, 120),
                                                   (2, 3000, 20, 5, 9, 33), (5, 3000, 2000, 16, 64, 64),
