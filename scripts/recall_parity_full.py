@@ -105,9 +105,9 @@ def main():
     phase[0] = "search of the CPU-built graph"
     with H.Builder(items, prev=og, load=True, M=M, M0=M0, ef_construction=ef) as b:
         rc = recalls(b)
-    first = next((e for e in efs if rc[e] >= 0.9), efs[-1])
+    first = next((e for e in efs if rc[e] >= 0.9), None)  # None: never, up to the largest ef_search tried
     out["recall_at_10"] = {str(e): {"gpu_built": rg[e], "cpu_built": rc[e], "diff": round(rg[e] - rc[e], 4)}
-                           for e in efs if e <= max(first, 100)}
+                           for e in efs if e <= max(first or efs[-1], 100)}
     out["ef_search_where_cpu_built_reaches_0.9"] = first
     out["within_half_percent"] = all(abs(v["diff"]) <= 0.005 for v in out["recall_at_10"].values())
     stop.set()
