@@ -13,7 +13,7 @@ typedef unsigned int u32;
 #define HNY_BIG_CAP 1024          // M0 of fresh builds / loaded graphs: lists are walked 64 slots at a time
 #define HNY_MAX_EPS 2048          // max entry points (every item of a small all-level-0 index is one)
 #define HNY_POOL_CAP 128          // tie pool (DESIGN.md "candidate heap")
-#define HNY_MAX_EF 512
+#define HNY_MAX_EF 65535         // ef_construction: result sets of ef + 1 entries, in the walk's LDS up to 4 096, in HBM beyond
 #define HNY_OP_INVALID 0xFFFFFFFFFFFFFFFFull
 // link-op sort key: layer:4 | target:31 | sequence:29 (levels 0..14: M = 4 draws up to level 14 before
 // its probability drops under the 1e-9 cut of get_default_probas, hnsw.rs:94-110)

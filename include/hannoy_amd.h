@@ -68,7 +68,7 @@ typedef struct {
                               * Anything wider: HNY_ERR_UNSUPPORTED, never a silently different
                               * graph.  (Incremental builds on lists of more than 64 slots read a
                               * per-record bitmap over all slots back: meant for small indexes.) */
-  uint32_t ef_construction;  /* default 100 (writer.rs:49) */
+  uint32_t ef_construction;  /* default 100 (writer.rs:49); 1 .. 65 535 (x86_order: result sets of at most 4 096 entries) */
   float alpha;               /* default 1.0 (writer.rs:51) */
   uint64_t seed;             /* levels when items.levels == NULL: drawn exactly as the reference
                               * draws them from StdRng::seed_from_u64(seed) (python.rs:261) */

@@ -293,7 +293,9 @@ def test_kat2_3_4_incremental_on_gpu(kat, orc, hny):
 @pytest.mark.parametrize("metric,dim,M,M0,ef,frac,bmax", [(1, 24, 6, 12, 32, 0.0, 1), (0, 48, 8, 16, 40, 0.1, 64),
                                                            (3, 128, 8, 16, 24, 0.1, 32),
                                                            (1, 40, 16, 100, 40, 0.1, 64),    # wide lists: k_fill_gaps_wg
-                                                           (0, 32, 16, 768, 32, 0.25, 256)])  # the fuzz test's pair and efC
+                                                           (0, 32, 16, 768, 32, 0.25, 256),   # the fuzz test's pair and efC
+                                                           (0, 32, 8, 16, 800, 0.25, 256),    # ef_construction > 512: LDS beams
+                                                           (1, 24, 8, 16, 5000, 0.25, 256)])  # ... and result sets in HBM
 def test_incremental_build_equals_oracle(orc, hny, metric, dim, M, M0, ef, frac, bmax):
     """Rounds of random deletes / overwrites / additions (2; HNY_TEST_INCR_ROUNDS for a longer soak):
     GPU == oracle edge for edge.  The last case is src/tests/fuzz.rs:83-143 restated: Cosine, 32 dims,
@@ -1441,6 +1443,27 @@ def test_m0_beyond_64_native_multi_gpu(orc, hny, monkeypatch):
     # the counters of the three ranks add up to the one-GPU build's (replicated work counted once)
     assert (g.n_evals_walk, g.n_evals_prune, g.n_evals_apply) == (g1.n_evals_walk, g1.n_evals_prune, g1.n_evals_apply)
     assert g.n_evals_walk == o.n_evals_walk and g.n_distance_evals == g1.n_distance_evals
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,kw", [
+    (0, 5000, 64, 16, 32, 600, dict(batch_frac=1.0, batch_max=2048)),
+    (3, 6000, 256, 8, 16, 1500, dict(batch_frac=1.0, batch_max=4096)),
+    (1, 2500, 768, 16, 32, 4095, dict(batch_frac=0.25, batch_max=512)),   # ef > n: every walk keeps the whole index
+    (0, 4000, 128, 12, 100, 1000, dict(batch_frac=1.0, batch_max=1024)),  # lists of more than 64 slots
+    (0, 9000, 48, 16, 32, 5000, dict(batch_frac=1.0, batch_max=1024)),    # result sets in HBM
+    (3, 7000, 128, 8, 16, 6500, dict(batch_frac=0.5, batch_max=2048)),
+])
+def test_ef_construction_beyond_512_equals_oracle(orc, hny, metric, n, dim, M, M0, ef, kw):
+    """ef_construction up to 4 095 (the reference takes any value, writer.rs:49): beams of more than 512 entries
+    live in the walk's LDS like the Reader's, robust_prune takes the candidate list from LDS or from HBM — the
+    graphs, link counts and walk evaluations are the oracle's; an update on top of it too."""
+    rng = np.random.default_rng(ef + n)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=2))
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
 def test_m0_limits_are_refused_loudly(orc, hny):
