@@ -19,6 +19,8 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 # SOAK_NMAX: largest index (default 2500; larger ones reach the locality-ordered batches and the XCD-tiled queue)
 ranks = int(os.environ.get("SOAK_RANKS", "0"))
 nmax = int(os.environ.get("SOAK_NMAX", "2500"))
+# SOAK_BIG_EF=1: half of the configurations with ef_construction 513 .. 7 000, half of the searches with ef_search up to 7 000
+big_ef = os.environ.get("SOAK_BIG_EF", "0") != "0"
 
 
 def same(g, o):
@@ -39,6 +41,8 @@ for ci in range(n_cfg):
       M0 = max(M0, M)
       n0 = int(rng.integers(400, nmax))
       ef = int(rng.integers(16, 90))
+      if big_ef and rng.random() < 0.5:
+          ef = int(rng.choice([513, 700, 1500, 4095, 4096, 7000]))
       frac = float(rng.choice([0.05, 0.25, 1.0]))
       bmax = int(rng.choice([16, 256, 4096] if nmax <= 2500 else [256, 4096, 16384]))
       clustered = rng.random() < 0.5
@@ -116,14 +120,17 @@ for ci in range(n_cfg):
       qh = orc.make_headers(metric, dim, qc)
       k = int(rng.integers(1, 20))
       efs = int(rng.integers(1, 120))
+      if big_ef and rng.random() < 0.5:
+          efs = int(rng.choice([513, 2000, 4095, 4096, 7000]))
+      efs_f = min(efs, 4000)  # with a candidates filter the result set stays in LDS
       items_s = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, np.zeros(0, np.uint8))
       cand = np.sort(rng.choice(ds.ids, max(1, len(ds.ids) // int(rng.integers(2, 40))), replace=False)).astype(np.uint32)
       with hny.Builder(items_s, prev=gg, load=True, M=M, M0=M0, ef_construction=ef) as b:
           gi, gd, gc = b.search_knn(qc, qh, k=k, ef_search=efs)
-          fi, fd, fc = b.nns(qc, qh, k=k, ef_search=efs, candidates=cand)
+          fi, fd, fc = b.nns(qc, qh, k=k, ef_search=efs_f, candidates=cand)
       oi, od, oc = orc.search(ds, gg, qc, qh, k=k, ef_search=efs, order=orc.ORDER_WAVE, threads=8)
       ok3 = np.array_equal(oc, gc) and np.array_equal(oi, gi) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
-      oi, od, oc = orc.search(ds, gg, qc, qh, k=k, ef_search=efs, order=orc.ORDER_WAVE, threads=8, candidates=cand)
+      oi, od, oc = orc.search(ds, gg, qc, qh, k=k, ef_search=efs_f, order=orc.ORDER_WAVE, threads=8, candidates=cand)
       ok3 = ok3 and np.array_equal(oc, fc) and np.array_equal(oi, fi)
       if not ok3:
           print("   search differs: k", k, "ef", efs, "counts equal", np.array_equal(oc, fc), flush=True)
