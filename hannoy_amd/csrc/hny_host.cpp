@@ -2221,8 +2221,11 @@ static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
                            out_counts, qo);
   if (b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "build not finished");
   const uint32_t k = qo->k, ef = std::max(qo->ef_search, k); // reader.rs:746, 837
-  if (ef + 1 > HNY_RES_LDS_MAX) // the filtered search keeps its result set in LDS
-    return fail(HNY_ERR_UNSUPPORTED, "ef_search %u with a candidates filter / by_item: at most %u", ef, HNY_RES_LDS_MAX - 1);
+  if ((uint64_t)ef + 1 > HNY_RES_GLOBAL_MAX)
+    return fail(HNY_ERR_UNSUPPORTED, "ef_search %u: result sets hold at most %u entries", ef, HNY_RES_GLOBAL_MAX - 1);
+  // k_nns_filtered keeps its result set in LDS (up to 4 096 entries); beyond that the same search runs with
+  // `res` as a heap in HBM next to the search queue's (k_nns_heap)
+  const bool big = ef + 1 > HNY_RES_LDS_MAX;
   HIP_TRY(hipSetDevice(b->device));
   const uint32_t n = b->n;
   auto exists = [&](uint32_t s) { return !b->incremental || !b->deleted[s]; };
@@ -2264,7 +2267,16 @@ static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
                                 b->o.M, b->stream));
     b->finalized = true;
   }
-  const uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes);
+  uint32_t rcap = res_capacity(ef, (uint32_t)b->entry_points.size(), b->n, b->top_layer_nodes,
+                               big ? HNY_RES_GLOBAL_MAX : HNY_RES_LDS_MAX);
+  if (big && linear) { // brute_force_search ranks in LDS: it returns min(k, candidates) hits
+    const uint64_t need = std::min<uint64_t>(k, cand_slots.size()) + 1;
+    if (need > HNY_RES_LDS_MAX)
+      return fail(HNY_ERR_UNSUPPORTED, "linear scan for %u hits among %zu candidates: at most %u (lower linear_below)", k,
+                  cand_slots.size(), HNY_RES_LDS_MAX - 1);
+    rcap = 64;
+    while (rcap < need) rcap *= 2;
+  }
   const size_t vb = vec_bytes(b->o.metric, b->o.dim), hb = hdr_bytes(b->o.metric);
   if (!by_item && qstride < vb) return fail(HNY_ERR_INVALID_DIM, "query stride too small");
   const uint32_t chunk = (uint32_t)std::max<uint64_t>(
@@ -2300,7 +2312,17 @@ static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
   const uint32_t heap_small = (uint32_t)std::min<uint64_t>((uint64_t)n + 1, 16384);
   const uint32_t heap_full = n + 1;
   uint32_t grid_small = std::min<uint32_t>(chunk, b->walk_slots);
-  if (!linear) HIP_TRY(dheap.alloc((size_t)grid_small * heap_small));
+  // big: queues with room for every item + the entry points and result heaps of rcap + 1, as many as 2 GB hold
+  const uint32_t heap_big_c = (uint32_t)std::min<uint64_t>((uint64_t)n + 1 + eps_cap_of(b), 0xFFFFFFFFull);
+  DevBuf<u64> dheap_r;
+  uint32_t grid_big = 0;
+  if (big && !linear) {
+    grid_big = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>(grid_small, ((uint64_t)2 << 30) / (((uint64_t)heap_big_c + rcap + 1) * 8)));
+    HIP_TRY(dheap.alloc((size_t)grid_big * heap_big_c));
+    HIP_TRY(dheap_r.alloc((size_t)grid_big * ((size_t)rcap + 1)));
+  } else if (!linear)
+    HIP_TRY(dheap.alloc((size_t)grid_small * heap_small));
   DevBuf<u64> dheap_full;
   uint32_t grid_full = 0;
   std::vector<float> qn(chunk);
@@ -2372,6 +2394,12 @@ static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     HIP_TRY(hipMemsetAsync(queues, 0, 8 * 4, b->stream));
     if (linear) {
       HIP_TRY(hnyk_nns_linear(b->g, a, b->shape, (int)std::min<uint32_t>(n_mem, b->walk_slots), b->stream));
+    } else if (big) {
+      a.heap = dheap.p;
+      a.heap_cap = heap_big_c;
+      a.heap_r = dheap_r.p;
+      a.heap_r_cap = rcap + 1;
+      HIP_TRY(hnyk_nns_heap(b->g, a, b->shape, (int)std::min<uint32_t>(n_mem, grid_big), b->stream));
     } else {
       a.heap = dheap.p;
       a.heap_cap = heap_small;

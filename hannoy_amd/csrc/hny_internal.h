@@ -155,6 +155,8 @@ struct NnsArgs {
   u32 log_cap;
   u64 *heap;                   // [grid][heap_cap]
   u32 heap_cap;
+  u64 *heap_r;                 // k_nns_heap: `res` as a heap too, [grid][heap_r_cap] (result sets beyond the LDS)
+  u32 heap_r_cap;
   u32 *queue;
   u32 vis_slots;               // LDS visited table entries per wave
   u32 eps_cap;                 // LDS entries of the eps array
@@ -219,6 +221,7 @@ hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, i
 hipError_t hnyk_prune(const GraphDev &g, const PruneArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
+hipError_t hnyk_nns_heap(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st);
 hipError_t hnyk_emit(const GraphDev &g, const EmitArgs &a, hipStream_t st);
 hipError_t hnyk_segments(const u64 *keys, u32 n_ops, u32 *seg_start, u32 *n_seg, hipStream_t st);
 hipError_t hnyk_apply(const GraphDev &g, const ApplyArgs &a, LaunchShape s, int grid, hipStream_t st);

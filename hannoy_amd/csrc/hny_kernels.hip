@@ -2220,6 +2220,242 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Visitor::visit at level 0 (reader.rs:301-369) with the search queue AND `res` as heaps in HBM: result sets
+// beyond the LDS (max(ef_search, k) >= 4 096 with a candidates filter / by_item — k_nns_filtered keeps `res`
+// as a sorted LDS array).  The queue takes every accepted point, `res` only what the filter lets through
+// (:322-324, :356-360); f_max = f32::MAX while `res` is empty (:337).  Returns 0, or 1 when a heap is full.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__device__ int visit_heap(const GraphDev &g, const float4 (&q)[NCH], float qn, int ef, const u32 *eps, int n_eps,
+                          QHeap &C, QHeap &R, Visited &vis, u32 *nb_ids, float *nb_d, const u32 *filter, u32 excl,
+                          u64 &evals, const unsigned char *qrow) {
+  const int ln = threadIdx.x;
+  C.size = 0;
+  C.top = ~0ull;
+  R.size = 0;
+  R.top = ~0ull;
+  for (int e0 = 0; e0 < n_eps; e0 += 64) { // :316-325 every entry point is queued and visited
+    const int ne = n_eps - e0 < 64 ? n_eps - e0 : 64;
+    u32 id = ln < ne ? eps[e0 + ln] : 0u;
+    bool isnew = visited_insert(vis, id, ln < ne);
+    u64 nmask = __ballot(isnew);
+    visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+    WSYNC();
+    if (ln < ne) nb_ids[ln] = id;
+    WSYNC();
+    dist_rows<LPR, NCH>(g, q, qn, nb_ids, ne, nb_d, qrow);
+    evals += (u64)ne;
+    WSYNC();
+    for (int r = 0; r < ne; r++) {
+      const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
+      if (!qheap_push(C, ((u64)db << 32) | (u64)(~idr))) return 1;
+      if (in_filter(filter, excl, idr) && !qheap_push(R, ~(((u64)db << 32) | (u64)idr))) return 1;
+    }
+  }
+  for (;;) {
+    if (C.size == 0) break;
+    const u64 top = C.top;
+    const float fmax = R.size ? __uint_as_float((u32)((~R.top) >> 32)) : 3.4028235e38f; // :337, once per pop
+    if (__uint_as_float((u32)(top >> 32)) > fmax) break;                                // raw f32 compare, :338
+    qheap_pop(C);
+    const u32 cslot = ~(u32)(top & 0xFFFFFFFFull);
+    for (int pass = g.incremental ? 0 : 1; pass < 2; pass++) {
+      u32 cap;
+      const u32 *nl = pass == 0 ? disk_ids(g, 0u, cslot, cap) : nbr_ids(g, 0u, cslot, cap);
+      if (!nl) continue;
+      for (u32 c0 = 0; c0 < cap; c0 += 64u) { // lists of more than 64 slots: 64 at a time, in order
+        u32 id = c0 + (u32)ln < cap ? nl[c0 + ln] : HNY_SENT;
+        bool valid = id != HNY_SENT;
+        bool isnew = visited_insert(vis, id, valid); // path.insert(point), :347
+        u64 nmask = __ballot(isnew);
+        if (!nmask) continue;
+        visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
+        if (g.incremental) {
+          isnew = isnew && g.has_vec[id] != 0;
+          nmask = __ballot(isnew);
+          if (!nmask) continue;
+        }
+        const int n_new = __popcll(nmask);
+        const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
+        WSYNC();
+        if (isnew) nb_ids[rank] = id;
+        WSYNC();
+        dist_rows<LPR, NCH>(g, q, qn, nb_ids, n_new, nb_d, qrow); // :350-353
+        evals += (u64)n_new;
+        WSYNC();
+        for (int r = 0; r < n_new; r++) { // ascending ids, like links.iter()
+          const u32 db = uni(fbits(nb_d[r])), idr = uni(nb_ids[r]);
+          if ((int)R.size < ef || __uint_as_float(db) < fmax) { // :357
+            if (!qheap_push(C, ((u64)db << 32) | (u64)(~idr))) return 1;
+            if (!in_filter(filter, excl, idr)) continue;
+            const u64 key = ((u64)db << 32) | (u64)idr;
+            if ((int)R.size == ef) { // push_pop_max: the new key, unless it is the greatest itself (or ef == 0)
+              if (R.size && key < ~R.top) {
+                qheap_pop(R);
+                if (!qheap_push(R, ~key)) return 1;
+              }
+            } else if (!qheap_push(R, ~key)) {
+              return 1;
+            }
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+// k_nns_filtered on heaps: same queries, same results, `res` of any length (NnsArgs.heap = the search queues,
+// heap_r = the result heaps; rows of a.cand hold up to rcap hits)
+template <int LPR, int NCH>
+__global__ __launch_bounds__(64, 4) void k_nns_heap(GraphDev g, NnsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u32 *nb_ids = reinterpret_cast<u32 *>(smem);
+  float *nb_d = reinterpret_cast<float *>(nb_ids + 64);
+  u32 *eps = reinterpret_cast<u32 *>(nb_d + 64);
+  const int ln = threadIdx.x, t = ln % LPR;
+  Visited vis;
+  visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words, a.vlog + (size_t)blockIdx.x * a.log_cap,
+               a.log_cap, nullptr, 0u);
+  QHeap C, R;
+  C.h = a.heap + (size_t)blockIdx.x * a.heap_cap;
+  C.cap = a.heap_cap;
+  R.h = a.heap_r + (size_t)blockIdx.x * a.heap_r_cap;
+  R.cap = a.heap_r_cap;
+  u64 evals = 0;
+  u32 log_over_cnt = 0;
+  for (;;) {
+    u32 mi = 0;
+    if (ln == 0) {
+      mi = atomicAdd(a.queue, 1u);
+      if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) mi = 0xFFFFFFFFu;
+    }
+    mi = uni(mi);
+    if (mi >= a.n_members) break;
+    const u32 m = a.members ? uni(a.members[mi]) : mi;
+    const unsigned char *qrow;
+    float qn = 0.f;
+    u32 excl = HNY_SENT;
+    if (a.by_item) { // :826-828 the stored vector is the query
+      excl = uni(a.q_slots[m]);
+      qrow = g.rows + (size_t)excl * g.row_stride;
+      if (g.norms) qn = g.norms[excl];
+    } else {
+      qrow = a.q_rows + (size_t)m * a.q_stride;
+      if (a.q_norms) qn = a.q_norms[m];
+    }
+    float4 q[NCH];
+    load_row<LPR, NCH>(qrow, t, g.n16, q);
+    int n_eps, st = 0;
+    u64 rmin = ~0ull;
+    if (a.by_item) { // Visitor::new(vec![item], 0, ef, Some(&candidates)), :842
+      n_eps = 1;
+      if (ln == 0) eps[0] = excl;
+      WSYNC();
+    } else { // :728-743 greedy descent, no filter, `path` shared and cleared before level 0
+      n_eps = (int)a.n_entry_points;
+      for (int i = ln; i < n_eps; i += 64) eps[i] = a.entry_points[i];
+      WSYNC();
+      for (u32 layer = g.max_level; layer >= 1u && !st; layer--) {
+        st = walk_layer_heap<LPR, NCH>(g, q, qn, layer, 1, eps, n_eps, C, R, rmin, vis, nb_ids, nb_d, evals, qrow);
+        const u32 closest = (u32)(rmin & 0xFFFFFFFFull);
+        WSYNC();
+        if (ln == 0) eps[0] = closest;
+        n_eps = 1;
+        if (layer == 1u) {
+          if (vis.log_over) log_over_cnt++;
+          visited_clear(vis);
+        }
+        WSYNC();
+      }
+    }
+    if (!st) st = visit_heap<LPR, NCH>(g, q, qn, (int)a.ef_main, eps, n_eps, C, R, vis, nb_ids, nb_d, a.filter, excl, evals, qrow);
+    u32 total = 0;
+    u64 *row = a.cand + (size_t)m * a.rcap;
+    auto drain = [&](u32 at) { // R, ascending, into row[at ..)
+      for (u32 i = R.size; i-- > 0u;) {
+        const u64 key = ~R.top;
+        if (ln == 0) row[at + i] = key;
+        qheap_pop(R);
+      }
+    };
+    if (!st) {
+      total = R.size;
+      if (total > a.rcap) {
+        st = 1;
+      } else {
+        drain(0u);
+        if (total < a.k) {
+          // exhaustive fallback (:771-795 / :864-890): restart from every item not on `path` yet
+          const u32 nwords = (g.n + 31) >> 5;
+          const u32 stop = a.by_item ? a.k : a.ef_opt;
+          u32 pos = 0;
+          visited_flush(vis);
+          while (pos < g.n) {
+            const u32 wbase = pos >> 5;
+            const u32 widx = wbase + (u32)ln;
+            u32 unv = 0u;
+            if (widx < nwords) {
+              unv = ~__hip_atomic_load(&vis.bits[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
+              if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
+            }
+            const u64 mk = __ballot(unv != 0u);
+            if (!mk) {
+              pos = (wbase + 64u) << 5;
+              continue;
+            }
+            const int l0 = __ffsll((long long)mk) - 1;
+            const u32 w0 = (u32)__builtin_amdgcn_readlane((int)unv, l0);
+            const u32 slot = ((wbase + (u32)l0) << 5) + (u32)__builtin_ctz(w0);
+            pos = slot + 1;
+            if (g.incremental && !g.has_vec[slot]) continue;
+            int ef2;
+            if (a.by_item) ef2 = (int)(a.k - total);                       // :878
+            else ef2 = a.ef_opt > total ? (int)(a.ef_opt - total) : 0;     // :783
+            WSYNC();
+            if (ln == 0) eps[0] = slot;
+            WSYNC();
+            st = visit_heap<LPR, NCH>(g, q, qn, ef2, eps, 1, C, R, vis, nb_ids, nb_d, a.filter, excl, evals, qrow);
+            if (st) break;
+            if (total + R.size > a.rcap) {
+              st = 1;
+              break;
+            }
+            const u32 got = R.size;
+            drain(total); // neighbours.extend(more_nns)
+            total += got;
+            if (total >= stop) break;
+          }
+          if (!st) { // drain_asc(): everything that was collected, sorted — through the heap once more
+            __threadfence_block();
+            WSYNC();
+            R.size = 0;
+            R.top = ~0ull;
+            for (u32 i = 0; i < total && !st; i++) {
+              const u64 key = uni64(row[i]);
+              if (!qheap_push(R, ~key)) st = 1;
+            }
+            if (!st) drain(0u);
+          }
+        }
+      }
+    }
+    if (ln == 0) {
+      a.cand_n[m] = st ? 0u : total;
+      a.status[m] = st ? 1u : 0u;
+    }
+    if (vis.log_over) log_over_cnt++;
+    visited_clear(vis);
+    WSYNC();
+  }
+  if (ln == 0) {
+    if (evals) atomicAdd(&g.stats[ST_EVALS_WALK], evals);
+    if (log_over_cnt) atomicAdd(&g.stats[ST_LOG_OVERFLOW], (u64)log_over_cnt);
+  }
+}
+
 // brute_force_search (reader.rs:667-711): rank the existing candidates by distance.  The
 // BinaryHeap keeps `count` entries and replaces its top only by a strictly smaller distance while
 // walking the ids upwards — i.e. it keeps the `count` smallest (bits(d), id) pairs, which does not
@@ -3854,6 +4090,14 @@ struct WalkHeapLauncher {
   }
 };
 template <int L, int C>
+struct NnsHeapLauncher {
+  static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
+    const size_t lds = 64 * 4 * 2 + (size_t)a.eps_cap * 4;
+    hipLaunchKernelGGL((k_nns_heap<L, C>), dim3(grid), dim3(64), lds, st, g, a);
+    return hipGetLastError();
+  }
+};
+template <int L, int C>
 struct NnsLinearLauncher {
   static hipError_t run(const GraphDev &g, const NnsArgs &a, int grid, hipStream_t st) {
     size_t lds = (size_t)a.rcap * 8 + 64 * 4 * 2;
@@ -3980,6 +4224,9 @@ hipError_t hnyk_walk_heap(const GraphDev &g, const WalkArgs &a, LaunchShape s, i
 }
 hipError_t hnyk_nns_filtered(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<NnsFilteredLauncher>(s, g, a, grid, st);
+}
+hipError_t hnyk_nns_heap(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
+  return dispatch_shape<NnsHeapLauncher>(s, g, a, grid, st);
 }
 hipError_t hnyk_nns_linear(const GraphDev &g, const NnsArgs &a, LaunchShape s, int grid, hipStream_t st) {
   return dispatch_shape<NnsLinearLauncher>(s, g, a, grid, st);

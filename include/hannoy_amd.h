@@ -269,7 +269,7 @@ int hny_builder_search_knn(hny_builder *b, uint64_t n_queries, const void *qvect
 #define HNY_NNS_NONE 0xFFFFFFFFu
 typedef struct {
   uint32_t k;                 /* Reader::nns(count) */
-  uint32_t ef_search;         /* default 100 (reader.rs:23); with candidates / by_item: max(ef_search, k) <= 4 095 */
+  uint32_t ef_search;         /* default 100 (reader.rs:23); max(ef_search, k) <= 65 535 (a linear scan returns at most 4 095 hits) */
   int32_t has_candidates;     /* .candidates() given (it may be empty) */
   const uint32_t *candidates; /* item ids, any order, duplicates and unknown ids allowed */
   uint64_t n_candidates;

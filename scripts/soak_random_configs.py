@@ -122,7 +122,7 @@ for ci in range(n_cfg):
       efs = int(rng.integers(1, 120))
       if big_ef and rng.random() < 0.5:
           efs = int(rng.choice([513, 2000, 4095, 4096, 7000]))
-      efs_f = min(efs, 4000)  # with a candidates filter the result set stays in LDS
+      efs_f = efs  # (the filtered search takes any ef_search too: k_nns_heap beyond 4 095)
       items_s = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, np.zeros(0, np.uint8))
       cand = np.sort(rng.choice(ds.ids, max(1, len(ds.ids) // int(rng.integers(2, 40))), replace=False)).astype(np.uint32)
       with hny.Builder(items_s, prev=gg, load=True, M=M, M0=M0, ef_construction=ef) as b:

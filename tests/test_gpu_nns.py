@@ -76,6 +76,40 @@ def test_filtered_search_equals_oracle(orc, hny, metric, n, dim, M, M0):
             _same(got, want)
 
 
+@pytest.mark.parametrize("metric,n,dim,M,M0", [(0, 6000, 64, 8, 16), (3, 7000, 64, 8, 16), (1, 5000, 24, 4, 8)])
+def test_filtered_and_by_item_search_with_result_sets_beyond_the_lds(orc, hny, metric, n, dim, M, M0):
+    """max(ef_search, k) >= 4 096 with a candidates filter / by_item: `res` no longer fits k_nns_filtered's LDS, the
+    same Visitor::visit runs with the search queue AND `res` as heaps in HBM (k_nns_heap) — ids, distances and
+    counts of the restated Reader; sparse filters reach the exhaustive fallback (reader.rs:771-795 / 864-890) there,
+    64-bit Hamming codes are all ties; the linear scan keeps its LDS ranking (min(k, candidates) hits)."""
+    ids = (np.arange(n, dtype=np.uint32) * 3 + 1)
+    rng, vecs, ds, b, g = _index(orc, hny, metric, n, dim, M, M0, 48, 31 + metric, ids)
+    qs, qc, qh = _queries(orc, metric, rng, 40, dim)
+    qi = np.concatenate([ids[rng.integers(0, n, 40)], [0, 2, 10 ** 7]]).astype(np.uint32)
+    with b:
+        for frac_kept in (0.9, 0.3, 0.01):
+            cand = ids[rng.random(n) < frac_kept]
+            cand = np.concatenate([cand, [0, 2, 10 ** 7]]).astype(np.uint32)
+            for k, ef in ((10, 4500), (4200, 100), (5, 7000)):
+                got = b.nns(qc, qh, k=k, ef_search=ef, candidates=cand, linear_below=0)
+                want = orc.search(ds, g, qc, qh, k=k, ef_search=ef, order=orc.ORDER_WAVE, threads=8,
+                                  candidates=cand, linear_below=0)
+                _same(got, want)
+                got = b.nns(k=k, ef_search=ef, query_items=qi, candidates=cand, linear_below=0)
+                want = orc.search(ds, g, None, None, k=k, ef_search=ef, order=orc.ORDER_WAVE, threads=8,
+                                  query_items=qi, candidates=cand, linear_below=0)
+                _same(got, want)
+        for k, ef in ((10, 4500), (4100, 10)):  # by_item without a filter
+            got = b.nns(k=k, ef_search=ef, query_items=qi)
+            want = orc.search(ds, g, None, None, k=k, ef_search=ef, order=orc.ORDER_WAVE, threads=8, query_items=qi)
+            _same(got, want)
+        cand = ids[rng.random(n) < 0.1]  # linear scan: below the default threshold of 1 000 candidates
+        got = b.nns(qc, qh, k=5000, ef_search=10, candidates=cand, linear_below=1000)
+        want = orc.search(ds, g, qc, qh, k=5000, ef_search=10, order=orc.ORDER_WAVE, threads=8, candidates=cand,
+                          linear_below=1000)
+        _same(got, want)
+
+
 @pytest.mark.parametrize("metric,n,dim,M,M0", [(0, 2000, 768, 16, 32), (1, 3000, 24, 4, 8), (3, 2500, 128, 8, 16)])
 def test_by_item_equals_oracle(orc, hny, metric, n, dim, M, M0):
     ids = (np.arange(n, dtype=np.uint32) * 2 + 5)
