@@ -331,7 +331,8 @@ enum { EV_WALK = 0, EV_PRUNE = 1, EV_SORT = 2, EV_APPLY = 3, EV_KINDS = 4 };
 // LDS visited table of a walk wave: what is left of a 10 KB share (16 waves per CU in 160 KB) after
 // the beam, in whole 64-entry rows
 static uint32_t eps_cap_of(const hny_builder *b) {
-  return (uint32_t)std::max<size_t>(64, (b->entry_points.size() + 63) / 64 * 64);
+  // entry points, or what robust_prune selected on the layer above: up to M for an item above level 0
+  return (uint32_t)std::max<size_t>(64, (std::max<size_t>(b->entry_points.size(), b->o.M) + 63) / 64 * 64);
 }
 // Entries of a walk's result set (beam).  walk_layer pushes every entry point without a capacity check
 // (hnsw.rs:474-481) and only evicts when res.len() == ef (:505-512): a walk that starts from MORE entry
@@ -671,7 +672,6 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   if (o.metric < 0 || o.metric > HNY_BQ_MANHATTAN) return fail(HNY_ERR_INVALID_ARG, "bad metric");
   if (o.dim == 0) return fail(HNY_ERR_INVALID_DIM, "dim must be > 0");
   if (o.M == 0 || o.M0 < o.M) return fail(HNY_ERR_INVALID_ARG, "need 1 <= M <= M0");
-  if (o.M > HNY_MAX_CAP) return fail(HNY_ERR_UNSUPPORTED, "M %u > %d", o.M, HNY_MAX_CAP);
   if (o.M0 > HNY_BIG_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_BIG_CAP);
   // 64 < M0 <= HNY_BIG_CAP: lists are walked 64 slots at a time and the workgroup kernels hold them
   // whole (incremental builds: k_fill_gaps_wg); strict mode's one-wave kernels keep one lane per slot

@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       const u64 *sl = a.sel + (size_t)m * a.sel_stride +
                       (size_t)(a.batch_level - (a.layer + 1)) * (a.cap_sel + 1);
       n_eps = (int)sl[0];
-      if (ln < n_eps) eps[ln] = (u32)(sl[1 + ln] & 0xFFFFFFFFull);
+      for (int i = ln; i < n_eps; i += 64) eps[i] = (u32)(sl[1 + i] & 0xFFFFFFFFull); // (more than 64: M > 64)
       start_layer = a.layer;
     }
     WSYNC();
@@ -2108,7 +2108,7 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
     } else { // :316-321 eps = what was selected on the layer above
       const u64 *sl = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - (a.layer + 1)) * (a.cap_sel + 1);
       n_eps = (int)sl[0];
-      if (ln < n_eps) eps[ln] = (u32)(sl[1 + ln] & 0xFFFFFFFFull);
+      for (int i = ln; i < n_eps; i += 64) eps[i] = (u32)(sl[1 + i] & 0xFFFFFFFFull); // (more than 64: M > 64)
       start_layer = a.layer;
     }
     WSYNC();

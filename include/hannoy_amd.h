@@ -58,8 +58,8 @@ enum {
 typedef struct {
   int32_t metric;            /* hny_metric */
   uint32_t dim;              /* user dimensions (binary codecs pad to 64, binary.rs:80-94) */
-  uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120).  1 <= M <= 64 and
-                              * M <= M0 <= 1024 in the wave order — fresh and incremental builds,
+  uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120).  1 <= M <= M0 <= 1024
+                              * in the wave order — fresh and incremental builds,
                               * loading / searching a stored graph; M0 <= 64 in strict mode
                               * (x86_order), whose one-wave kernels keep one lane per neighbour slot.
                               * That covers every pair the reference's Python API offers ((4,8) ..

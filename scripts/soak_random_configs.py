@@ -38,6 +38,10 @@ for ci in range(n_cfg):
       dim = int(rng.choice([3, 20, 48, 100, 128, 300, 768, 1024]))
       M = int(rng.choice([4, 8, 12, 16, 24, 32]))
       M0 = int(rng.choice([M, 2 * M, 2 * M + 1, 70, 100, 200, 333, 768])) if rng.random() < 0.7 else 2 * M
+      lvM = M
+      if big_ef and rng.random() < 0.25:  # M beyond one wave's lanes; levels drawn as for M = 4 so that upper layers fill
+          M = int(rng.choice([65, 80, 128]))
+          lvM = 4
       M0 = max(M0, M)
       n0 = int(rng.integers(400, nmax))
       ef = int(rng.integers(16, 90))
@@ -62,7 +66,7 @@ for ci in range(n_cfg):
           ids = np.array(sorted(vecs), np.uint32)
           mat = np.stack([vecs[int(i)] for i in ids])
           return orc.Dataset.from_f32(metric, mat, levels if levels is not None else np.zeros(len(ids), np.uint8), ids)
-      ds = mk(draw_levels(n0, M, seed=ci))
+      ds = mk(draw_levels(n0, lvM, seed=ci))
       hist = dict(params=np.array([metric, dim, M, M0, ef, bmax], np.int64), frac=np.array([frac]), ids0=ds.ids.copy(), mat0=np.stack([vecs[int(i)] for i in ds.ids]), lv0=np.asarray(ds.levels).copy())
       items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
       og = orc.build(ds, **kw_o)
@@ -95,7 +99,7 @@ for ci in range(n_cfg):
           for i, v in zip(added, vec(len(added))):
               vecs[i] = v
           to_insert = sorted(overwrite + added)
-          lv = draw_levels(len(to_insert), M, seed=100 * (rnd + 1) + ci)
+          lv = draw_levels(len(to_insert), lvM, seed=100 * (rnd + 1) + ci)
           if rng.random() < 0.3:
               lv = np.zeros(len(to_insert), np.uint8)  # every new item on level 0 (hnsw.rs:278-285)
           ds2 = mk(None)

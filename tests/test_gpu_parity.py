@@ -1466,12 +1466,59 @@ def test_ef_construction_beyond_512_equals_oracle(orc, hny, metric, n, dim, M, M
     assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,lvM", [(0, 3000, 300, 80, 160, 64, 4), (1, 2000, 256, 100, 100, 120, 3),
+                                                       (3, 2500, 128, 128, 256, 48, 4), (0, 1500, 200, 65, 65, 700, 2)])
+def test_m_beyond_64_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, ef, lvM):
+    """M > 64 (the reference's const generics take any pair, writer.rs:215-220): an item above level 0 selects up
+    to M neighbours, which are the entry points of its walk one layer down — more than one wave's lanes — and the
+    upper layers' lists hold more than 64 links.  Levels are drawn as for a small M so that the upper layers
+    are populated.  Fresh build, an update, a search, and the build once more through the heap walk."""
+    rng = np.random.default_rng(M + n)
+    vecs = {i: rng.uniform(-1, 1, dim).astype(np.float32) for i in range(n)}
+
+    def mk(levels):
+        ids = np.array(sorted(vecs), np.uint32)
+        return orc.Dataset.from_f32(metric, np.stack([vecs[int(i)] for i in ids]), levels, ids)
+    ds = mk(draw_levels(n, lvM, seed=7))
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    kw = dict(batch_frac=0.5, batch_max=512)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+    d = o.as_dict()
+    if M >= 80:
+        assert max(len(v) for (i, l), v in d.items() if l >= 1) > 64  # upper-layer lists beyond one wave's lanes
+    to_delete = sorted(rng.choice(n, n // 10, replace=False).tolist())
+    for i in to_delete:
+        del vecs[i]
+    to_insert = list(range(n, n + n // 5))
+    for i in to_insert:
+        vecs[i] = rng.uniform(-1, 1, dim).astype(np.float32)
+    lv = draw_levels(len(to_insert), lvM, seed=8)
+    ds2 = mk(np.zeros(len(vecs), np.uint8))
+    items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, lv)
+    o2 = orc.build_incremental(ds2, o, to_insert, lv, to_delete, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, **kw)
+    g2 = hny.build_incremental(items2, g, to_insert, to_delete, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g2, o2)
+    qs = rng.uniform(-1, 1, (50, dim)).astype(np.float32)
+    qc = orc.encode_vectors(metric, qs)
+    qh = orc.make_headers(metric, dim, qc)
+    with hny.Builder(items2, prev=g2, load=True, M=M, M0=M0, ef_construction=ef) as b:
+        got = b.search_knn(qc, qh, k=10, ef_search=80)
+    want = orc.search(ds2, g2, qc, qh, k=10, ef_search=80, order=orc.ORDER_WAVE, threads=8)
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
+    monkeypatch.setenv("HNY_POOL_FORCE_RETRY", "2")
+    g3 = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g3, o)
+
+
 def test_m0_limits_are_refused_loudly(orc, hny):
-    """include/hannoy_amd.h: M <= 64, M0 <= 1024 in the wave order, M0 <= 64 in strict mode:
+    """include/hannoy_amd.h: M <= M0 <= 1024 in the wave order, M0 <= 64 in strict mode:
     HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
     v = np.random.default_rng(1).uniform(-1, 1, (500, 32)).astype(np.float32)
     items = hny.ItemSet.from_f32(hny.COSINE, v)
-    for kw in (dict(M=16, M0=1025), dict(M=65, M0=65), dict(M=16, M0=96, x86_order=True)):
+    for kw in (dict(M=16, M0=1025), dict(M=1025, M0=1025), dict(M=80, M0=160, x86_order=True), dict(M=16, M0=96, x86_order=True)):
         with pytest.raises(hny.HannoyError) as e:
             hny.build(items, ef_construction=32, **kw)
         assert e.value.code == -5
