@@ -687,6 +687,20 @@ __device__ __forceinline__ u64 wave_min_step(u64 v) {
 }
 __device__ __forceinline__ u64 wave_min_u64(u64 v) { return wave_min_step<32>(v); }
 
+// Every field below is wave-uniform by construction, but the compiler cannot always prove it: a lane-conditional
+// store (`if (ln == 0) pool[i] = key`) that ends a uniform region makes the join behind it a "divergent" phi for
+// whatever else is merged there, and from then on every `if (s.pool_len > 0)`, every loop exit, is compiled as
+// exec-mask arithmetic (s_and_saveexec / s_andn2 / s_or / s_cbranch_execz) instead of one scalar branch — ~400
+// of the ~430 scalar instructions of a C5 expansion were that.  settle() pins the state back into SGPRs.
+__device__ __forceinline__ void settle(Beam &s) {
+  s.res_len = uni(s.res_len);
+  s.pool_len = uni(s.pool_len);
+  s.n_weird = uni(s.n_weird);
+  s.tie_bits = uni(s.tie_bits);
+  s.dropped = uni((int)s.dropped) != 0;
+  s.pool_over = uni(s.pool_over);
+  s.err = uni(s.err);
+}
 __device__ __forceinline__ void pool_push(Beam &s, u64 key) {
   if (s.pool_len < HNY_POOL_CAP) {
     if (HNY_LANE == 0) s.pool[s.pool_len] = key & ~1ull;
@@ -696,6 +710,7 @@ __device__ __forceinline__ void pool_push(Beam &s, u64 key) {
   } else {
     s.pool_over++;
   }
+  settle(s);
 }
 
 // res.max moved below the ordinary pool entries: they can never be popped before the break
@@ -718,6 +733,7 @@ __device__ __forceinline__ void pool_drop_ties(Beam &s) {
   if (k1) s.pool[__popcll(m0) + __popcll(m1 & lt)] = a1;
   s.pool_len = __popcll(m0) + __popcll(m1);
   WSYNC();
+  settle(s);
 }
 
 // an entry leaves res (push_pop_max); nd = distance bits of the res.max that remains
@@ -805,6 +821,7 @@ __device__ __forceinline__ u64 rb_shift_up(u64 v, u64 lane0) {
 template <int RC>
 __device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR<RC> &r, u64 key, int ef) {
   const int ln = HNY_LANE;
+  settle(s);
   const int len = s.res_len;
   int pos = 0;
 #pragma unroll
@@ -849,6 +866,7 @@ __device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR<RC> &r, u64 key, i
 template <int RC>
 __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u64 key, int ef) {
   const int ln = HNY_LANE;
+  settle(s);
   const int len = s.res_len;
   u64 m = __ballot(acc);
   const int A = __popcll(m);
@@ -927,6 +945,7 @@ __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u
       s.pool_len += nput;
       s.pool_over += (u32)(np - nput);
       WSYNC();
+      settle(s);
     }
   }
 }
@@ -1073,6 +1092,14 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
   WSYNC();
 }
 
+__device__ __forceinline__ void settle(Visited &v) {
+  v.log_len = uni(v.log_len);
+  v.log_over = uni((int)v.log_over) != 0;
+  v.count = uni(v.count);
+  v.spill = uni((int)v.spill) != 0;
+  v.in_bits = uni((int)v.in_bits) != 0;
+}
+
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
 // QN != NCH: the query is held 8 lanes per row (dist_rows_narrow)
 // LMERGE: the LDS beam (RC == 0) takes the accepted keys of an expansion in one batched merge
@@ -1117,6 +1144,9 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     }
   }
   for (u32 iter = 0;; iter++) {
+    settle(s);
+    settle(vis);
+    evals = uni(evals);
     if (iter > 200000u || s.err) {
       if (iter > 200000u) err_iter = 1;
       break;
@@ -1314,6 +1344,290 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// walk_layer for SHORT rows (at most 512 B: eight lanes per row), the beam in registers, the visited set
+// the per-wave bitset, a fresh build's lists (M0 <= 64) — the specialised kernels' case for 128-d f32 and
+// binary codes (BASELINE C4 / C5).  The algorithm is walk_one_layer's, statement for statement; what differs
+// is what the instruction stream of one expansion costs.  Round 3 left that kernel at ~480 vector + ~430
+// scalar instructions per expansion of ~10 rows of 128 B, i.e. bound by instruction issue, and round 4's
+// reading of the compiler's own uniformity analysis (scripts/isa_report.py) showed why: the beam / pool /
+// visited counters came out of the expansion loop as "divergent" values, so every `if (pool_len > 0)`, every
+// loop exit, was exec-mask arithmetic.  Here
+//   * all loop-carried state is pinned wave-uniform (settle()), branches on it are scalar;
+//   * the tie pool is only scanned when it can win the pop: its ordinary entries all sit at distance
+//     `tie_bits` == res.max, so while the first unexpanded entry of res is closer the pool is not looked at
+//     (C5: the pool is non-empty in 2 of 3 expansions and wins almost never);
+//   * the distances are consumed where the reduction leaves them — lane 8*sub + 4*j of row 8*j + sub —
+//     and the accept test `dist < f_max` (hnsw.rs:505) is applied there: no round trip through LDS, no
+//     second compaction; the (<= 4) chunks of 16 rows are interleaved by a DPP row shift so that ONE merge
+//     serves the expansion;
+//   * lane-conditional LDS traffic is predicated by address (a dump slot) instead of by exec mask.
+// ---------------------------------------------------------------------------------------------
+// distances of rows ids[k0 .. k0 + 16) (as far as they are < n) to the query: the lane with (t & 3) == 0 of
+// lane group `sub` returns row ri = k0 + 8 * (t >> 2) + sub (wave order of an LPRO-lane row group, computed
+// by 8 lanes exactly as dist_rows_narrow does; LPRO == 8 is the plain 8-lane butterfly)
+template <int LPRO>
+__device__ __forceinline__ void dist16(const GraphDev &g, const float4 (&q)[LPRO / 8], float qn, const u32 *ids,
+                                       int n, int k0, float &d, u32 &rid, int &ri) {
+  constexpr int NQ = LPRO / 8;
+  const int ln = HNY_LANE, t = ln & 7, sub = ln >> 3;
+  const int j = (t >> 2) & 1; // fold2_row<8>()
+  float4 r[2][NQ];
+  float rn[2];
+  u32 rids[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    int x = k0 + u * 8 + sub;
+    x = x < n - 1 ? x : n - 1;
+    rids[u] = ids[x];
+  }
+  const bool two = k0 + 8 < n; // wave-uniform: the second load group holds rows
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    rn[u] = 0.f;
+    if (u == 0 || two) {
+      const unsigned char *p = g.rows + (size_t)rids[u] * g.row_stride;
+#pragma unroll
+      for (int c = 0; c < NQ; c++) {
+        const u32 f = (u32)(c * 8 + t);
+        r[u][c] = f < g.n16 ? *reinterpret_cast<const float4 *>(p + (size_t)f * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (g.norms) rn[u] = g.norms[rids[u]];
+    } else {
+#pragma unroll
+      for (int c = 0; c < NQ; c++) r[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // fold2 on both groups always: for the rows of group 0 its pair sums are the butterfly's (a second group
+  // of zeros only feeds the lanes of rows that do not exist)
+  if (g.mclass == MC_BIN) {
+    const u32 y = fold2<8, u32>(partial_bin<NQ>(q, r[0]), partial_bin<NQ>(q, r[1]));
+    d = finalize_bin(g, y, qn, j ? rn[1] : rn[0]);
+  } else {
+    float pa[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      float pu[NQ];
+#pragma unroll
+      for (int c = 0; c < NQ; c++) {
+        const float4 qc[1] = {q[c]}, rc[1] = {r[u][c]};
+        pu[c] = partial_f32<1>(g.mclass, qc, rc);
+      }
+      if constexpr (NQ == 4) pa[u] = (pu[0] + pu[2]) + (pu[1] + pu[3]); // off = 16, then off = 8
+      else if constexpr (NQ == 2) pa[u] = pu[0] + pu[1];                // off = 8
+      else pa[u] = pu[0];
+    }
+    d = finalize_f32(g, fold2<8, float>(pa[0], pa[1]), qn, j ? rn[1] : rn[0]);
+  }
+  rid = j ? rids[1] : rids[0];
+  ri = k0 + j * 8 + sub;
+}
+
+// value of lane - K within its row of 16 lanes (v_mov_b32_dpp row_shr:K); lanes without a source get 0
+template <int K>
+__device__ __forceinline__ u32 row_shr(u32 v) {
+  if constexpr (K == 0) return v;
+  else return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xF, 0xF, false);
+}
+
+template <int LPRO>
+__device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4 (&q)[LPRO / 8], float qn, u32 layer,
+                                                 int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
+                                                 u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
+                                                 BeamR<2> &rb) {
+  const int ln = HNY_LANE, t = ln & 7;
+  const u64 lt = (1ull << ln) - 1ull;
+  u32 *dump = reinterpret_cast<u32 *>(nb_d); // 64 words behind nb_ids: where the lanes without a new id write
+  s.res_len = 0;
+  s.pool_len = 0;
+  s.n_weird = 0;
+  s.tie_bits = 0;
+  s.dropped = false;
+  // :474-481 every entry point goes to candidates and res (no capacity check) and is visited
+  {
+    const int ne = n_eps; // <= 64 here
+    u32 id = eps[ln < ne ? ln : 0];
+    bool isnew = visited_insert(vis, id, ln < ne);
+    u64 nmask = __ballot(isnew);
+    visited_log(vis, id, isnew, nmask, __popcll(nmask & lt));
+    nb_ids[ln] = id;
+    WSYNC();
+    for (int k0 = 0; k0 < ne; k0 += 16) {
+      float d;
+      u32 rid;
+      int ri;
+      dist16<LPRO>(g, q, qn, nb_ids, ne, k0, d, rid, ri);
+      if ((t & 3) == 0 && ri < ne) dump[ri] = fbits(d);
+    }
+    evals += (u64)ne;
+    WSYNC();
+    for (int r = 0; r < ne; r++) {
+      const u64 key = ((u64)uni(dump[r]) << 32) | ((u64)uni(nb_ids[r]) << 1);
+      beam_insert_rb<2>(s, rb, key, 0x7FFFFFFF);
+    }
+    WSYNC();
+  }
+  for (u32 iter = 0;; iter++) {
+    settle(s);
+    settle(vis);
+    evals = uni(evals);
+    if (iter > 200000u || s.err) {
+      if (iter > 200000u) err_iter = 1;
+      break;
+    }
+#ifdef HNY_PHASE_CLOCKS
+    s.ph_t = __builtin_readcyclecounter();
+    s.ph[4]++;
+#endif
+    // ---- candidates.peek()/pop(): smallest distance bits, larger id first among equals
+    // (BinaryHeap<(Reverse<OrderedFloat>, ItemId)>, :469, :483-488)
+    const int len = s.res_len;
+    const bool un0 = ln < len && !(rb.r[0] & 1ull), un1 = ln + 64 < len && !(rb.r[1] & 1ull);
+    const u64 m0 = __ballot(un0), m1 = __ballot(un1);
+    const u32 dmax = (u32)(rb_get<2>(rb, len - 1) >> 32);
+    const bool have_a = (m0 | m1) != 0ull;
+    int last = -1;
+    u32 d0 = 0u;
+    u64 ta = ~0ull;
+    if (have_a) { // pop-order key: distance bits ascending, then id DESCENDING
+      const int first_un = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
+      d0 = (u32)(rb_get<2>(rb, first_un) >> 32);
+      const u64 t0 = __ballot(un0 && (u32)(rb.r[0] >> 32) == d0), t1 = __ballot(un1 && (u32)(rb.r[1] >> 32) == d0);
+      last = t1 ? 64 + 63 - __clzll((long long)t1) : 63 - __clzll((long long)t0);
+      ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get<2>(rb, last) & 0xFFFFFFFEull));
+    }
+    u64 tp = ~0ull;
+    int pi = -1;
+    // The ordinary pool entries all carry the distance bits `tie_bits` == those of res.max (beam_evicted,
+    // pool_drop_ties), so they precede the first unexpanded entry of res in pop order only if that one is
+    // not closer; weird entries (sign bit / NaN) sort behind every ordinary distance.
+    if (s.pool_len > 0 && (!have_a || s.n_weird > 0 || d0 >= s.tie_bits)) {
+      static_assert(HNY_POOL_CAP == 128, "two pool entries per lane");
+      const bool h0 = ln < s.pool_len, h1 = ln + 64 < s.pool_len;
+      const u64 k0 = s.pool[ln], k1 = s.pool[ln + 64];
+      const u64 p0 = h0 ? ((k0 & 0xFFFFFFFF00000000ull) | (u64)(~(u32)(k0 & 0xFFFFFFFFull))) : ~0ull;
+      const u64 p1 = h1 ? ((k1 & 0xFFFFFFFF00000000ull) | (u64)(~(u32)(k1 & 0xFFFFFFFFull))) : ~0ull;
+      const bool second = h1 && p1 < p0;
+      const u64 mine = second ? p1 : p0;
+      tp = uni(wave_min_u64(mine));
+      const int wl = __ffsll((long long)__ballot(h0 && mine == tp)) - 1; // h0: the lane holds an entry at all
+      pi = wl + (((__ballot(second) >> wl) & 1ull) ? 64 : 0);
+    }
+    const bool have_p = pi >= 0;
+    if (!have_a && !have_p) break; // candidates exhausted (or only dropped entries: they break)
+    const bool use_pool = have_p && (!have_a || tp < ta);
+    const u32 fb = (u32)((use_pool ? tp : ta) >> 32);
+    // a dropped ordinary candidate precedes every weird one in pop order and breaks the walk
+    if (use_pool && weird_bits(fb) && s.dropped) break;
+    if (__uint_as_float(fb) > __uint_as_float(dmax)) break; // raw f32 compare, :485
+    u32 cslot;
+    if (use_pool) {
+      cslot = (~(u32)(tp & 0xFFFFFFFFull)) >> 1;
+      const u64 lastk = uni(s.pool[s.pool_len - 1]);
+      WSYNC();
+      if (ln == 0) s.pool[pi] = lastk;
+      s.pool_len--;
+      if (weird_bits(fb)) s.n_weird--;
+      WSYNC();
+      settle(s);
+    } else {
+      cslot = (u32)(rb_get<2>(rb, last) >> 1) & 0x7FFFFFFFu;
+      rb.r[0] |= (u64)(ln == last);
+      rb.r[1] |= (u64)(ln + 64 == last);
+    }
+    const float fmax = __uint_as_float(dmax); // f_max captured once per pop (:484)
+    PH_STAMP(s, 0);
+
+    // ---- neighbours of c (:491-495): the in-memory list (fresh build), one lane per slot
+    u32 cap;
+    const u32 *nl = nbr_ids(g, layer, cslot, cap);
+    u32 id = nl[(u32)ln < cap ? (u32)ln : cap - 1u];
+    const bool valid = (u32)ln < cap && id != HNY_SENT;
+    bool isnew = false;
+    if (valid) {
+      const u32 b = 1u << (id & 31);
+      isnew = !(atomicOr(&vis.bits[id >> 5], b) & b);
+    }
+    u64 nmask = __ballot(isnew);
+    if (!nmask) {
+      PH_STAMP(s, 1);
+      continue;
+    }
+    {
+      const int n_log = __popcll(nmask);
+      if (vis.log_len + (u32)n_log <= vis.log_cap) {
+        if (isnew) vis.vlog[vis.log_len + (u32)__popcll(nmask & lt)] = id;
+      } else {
+        vis.log_over = true;
+      }
+      vis.log_len += (u32)n_log;
+    }
+    if (len < ef) {
+      // duplicates inside one list (add_link never dedups, hnsw.rs:521): while res is not full
+      // the order of acceptance matters, so the FIRST occurrence must be the one that counts
+      nb_ids[ln] = valid ? id : HNY_SENT;
+      WSYNC();
+      int firstj = ln;
+      bool anynew = isnew;
+      for (int j = 0; j < (int)cap; j++) {
+        const u32 oj = nb_ids[j];
+        if (valid && oj == id) {
+          if (j < firstj) firstj = j;
+          if ((nmask >> j) & 1ull) anynew = true;
+        }
+      }
+      isnew = valid && anynew && firstj == ln;
+      WSYNC();
+      nmask = uni64(__ballot(isnew));
+    }
+    const int n_new = __popcll(nmask);
+    nb_ids[isnew ? __popcll(nmask & lt) : 64 + ln] = id; // (64 + ln: the dump words)
+    WSYNC();
+    PH_STAMP(s, 1);
+    // ---- :503-512 score the new points, keep those that enter res
+    int room = ef - len;
+    if (room < 0) room = 0;
+    u32 acc = 0u, khi = 0u, klo = 0u;
+#define HNY_SHORT_CHUNK(K)                                                                   \
+    if (16 * K < n_new) {                                                                    \
+      float d;                                                                               \
+      u32 rid;                                                                               \
+      int ri;                                                                                \
+      dist16<LPRO>(g, q, qn, nb_ids, n_new, 16 * K, d, rid, ri);                             \
+      /* :505 `res.len() < ef || dist < f_max` — the first `room` new points regardless */   \
+      const bool a = (t & 3) == 0 && ri < n_new && (ri < room || d < fmax);                  \
+      const u32 ak = row_shr<K>(a ? 1u : 0u), hk = row_shr<K>(fbits(d)), lk = row_shr<K>(rid << 1); \
+      if ((t & 3) == K) {                                                                    \
+        acc = ak;                                                                            \
+        khi = hk;                                                                            \
+        klo = lk;                                                                            \
+      }                                                                                      \
+    }
+    HNY_SHORT_CHUNK(0)
+    HNY_SHORT_CHUNK(1)
+    HNY_SHORT_CHUNK(2)
+    HNY_SHORT_CHUNK(3)
+#undef HNY_SHORT_CHUNK
+    evals += (u64)n_new;
+    PH_STAMP(s, 2);
+    u64 amask = __ballot(acc != 0u);
+    if (!amask) continue;
+    if (__popcll(amask) >= HNY_RB_MERGE_MIN && HNY_RB_MERGE) { // one key: the plain insert is cheaper
+      beam_merge_rb<2>(s, rb, acc != 0u, ((u64)khi << 32) | (u64)klo, ef);
+      amask = 0ull;
+    }
+    while (amask) {
+      const int r = __ffsll((long long)amask) - 1;
+      amask &= amask - 1ull;
+      const u32 db = (u32)__builtin_amdgcn_readlane((int)khi, r);
+      const u32 idr = (u32)__builtin_amdgcn_readlane((int)klo, r);
+      beam_insert_rb<2>(s, rb, ((u64)db << 32) | (u64)idr, ef);
+    }
+    PH_STAMP(s, 3);
+  }
+}
+
+
 #ifndef HNY_WALK_WPE
 #define HNY_WALK_WPE 4
 #endif
@@ -1334,6 +1648,12 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   constexpr int QN = NARROW ? LPR / 8 : NCH;
   constexpr bool LMERGE = SP != 0 && RC == 0 && !BIG_EPS; // specialised kernels with the beam in LDS
   constexpr bool PAGED = SP == 0;                          // general kernels: M0 up to HNY_BIG_CAP
+  // rows of at most 32 units with the beam in registers: walk_layer_short (HNY_NO_SHORT_WALK: walk_one_layer)
+#ifdef HNY_NO_SHORT_WALK
+  constexpr bool SHORT = false;
+#else
+  constexpr bool SHORT = SP != 0 && RC == 2 && NCH == 1 && LPR <= 32;
+#endif
   GraphDev g = g_in;
   WalkArgs a = a_in;
   specialize<SP>(g);
@@ -1461,13 +1781,21 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       for (int i = ln; i < n_eps; i += 64) eps[i] = (u32)(sl[1 + i] & 0xFFFFFFFFull); // (more than 64: M > 64)
       start_layer = a.layer;
     }
+    // the lane-conditional stores above sit on the paths that define these two: without the readfirstlane the
+    // compiler's uniformity analysis calls them divergent, and with them the layer loop's exit, `ef`, and
+    // every piece of beam / pool / visited state that the expansion loop carries
+    n_eps = uni(n_eps);
+    start_layer = uni(start_layer);
     WSYNC();
     u64 lkey = 0;
     for (u32 layer = start_layer;; layer--) {
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
-      walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
-                                   nb_d, evals, err_iter, qrow, rb);
+      if constexpr (SHORT)
+        walk_layer_short<LPR>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, rb);
+      else
+        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+                                     nb_d, evals, err_iter, qrow, rb);
       if (last) break;
       // :305-306 eps = [closest]
       const u32 closest = RB ? (u32)(rb_get<RCN>(rb, 0) >> 1) & 0x7FFFFFFFu : uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
@@ -1544,7 +1872,10 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
-        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        if constexpr (SHORT)
+          walk_layer_short<LPR>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, rb);
+        else
+          walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
@@ -3942,6 +4273,9 @@ template <template <int, int> class Launcher, typename... Args>
 hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
 #define HNY_CASE(L, C) \
   if (s.lpr == L && s.nch == C) return Launcher<L, C>::run(args...);
+#ifdef HNY_ONLY_LPR // diagnostics (scripts/isa_report.py): one row shape only, so that one kernel compiles in seconds
+  HNY_CASE(HNY_ONLY_LPR, HNY_ONLY_NCH)
+#else
   HNY_CASE(8, 1)
   HNY_CASE(16, 1)
   HNY_CASE(32, 1)
@@ -3953,6 +4287,7 @@ hipError_t dispatch_shape(LaunchShape s, Args &&...args) {
   HNY_CASE(64, 8)
   HNY_CASE(64, 12)
   HNY_CASE(64, 16)
+#endif
 #undef HNY_CASE
   return hipErrorInvalidValue;
 }
