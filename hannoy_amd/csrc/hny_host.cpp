@@ -363,11 +363,33 @@ static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
   // the longer probes outweigh the saved L2 atomics when a row costs little; round 2, 5M x 1024 bits:
   // 0.73-0.91 s against 0.66 s): rows > 1 KB only — the specialised short-row kernels are compiled
   // without the table
-  if ((size_t)b->g.n16 * 16 <= 1024) return 0;
+  if ((size_t)b->g.n16 * 16 <= 1024) { // experiment (needs a library built with -DHNY_SHORT_TAB)
+    const char *e = getenv("HNY_SHORT_TAB");
+    return e && *e ? (uint32_t)std::max(0, atoi(e)) : 0u;
+  }
   if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
   const size_t fixed = hnyk_walk_lds_bytes(rcap, eps_cap_of(b));
   if (fixed + 512 * 4 > 10240) return 512;
   return (uint32_t)((10240 - fixed) / 4 / 64 * 64);
+}
+// Short rows (<= 512 B, walk_layer_short): the LDS visited table of 16-bit remainders.  As many buckets as keep
+// the walk's occupancy: 8 KB of LDS per wave at 5 waves per SIMD (binary codes), 10 KB at 4 (f32) — and only
+// while a remainder fits 16 bits (2^k / buckets < 65 535, n < 2^28).  HNY_VIS_BUCKETS overrides (0 = bitset only).
+static void vis_buckets_for(const hny_builder *b, WalkArgs &w) {
+  w.vis_buckets = w.vis_magic = w.vis_smask = 0;
+  if ((size_t)b->g.n16 * 16 > 512 || w.vis_slots || w.res_global || w.rcap > 128 || w.eps_cap > 64) return;
+  const size_t fixed = hnyk_walk_lds_bytes(w.rcap, w.eps_cap);
+  const size_t budget = (b->shape.nch == 1 && b->o.metric >= HNY_HAMMING) ? 8192 : 10240;
+  int nb = fixed + 1024 <= budget ? (int)((budget - fixed) / 8 / 64 * 64) : 0;
+  const char *e = getenv("HNY_VIS_BUCKETS");
+  if (e && *e) nb = std::max(0, std::min(4096, atoi(e) / 2 * 2));
+  if (nb < 64) return;
+  uint32_t k = 1;
+  while (k < 28 && (1ull << k) < (uint64_t)std::max<uint32_t>(b->g.n, 2)) k++;
+  if ((1ull << k) < (uint64_t)b->g.n || ((1ull << k) - 1) / (uint64_t)nb + 1 >= 65535) return;
+  w.vis_buckets = (u32)nb;
+  w.vis_magic = (u32)((1ull << 40) / (uint64_t)nb + 1);
+  w.vis_smask = (u32)((1ull << k) - 1);
 }
 static void prof_begin(hny_builder *b, int kind, hipStream_t st = nullptr) {
   if (!b->profiling) return;
@@ -1183,6 +1205,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.eps_cap = eps_cap_of(b);
     w.queue = queue;
     w.res_global = b->d_res_global.p; // null unless the result sets outgrow the LDS (res_capacity)
+    vis_buckets_for(b, w);
     return w;
   };
   auto prune_args = [&](int32_t l, uint32_t clo, uint32_t chi) {
@@ -1689,6 +1712,9 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   fprintf(stderr, "[hny] walk wave cycles: pop %llu list+visited %llu distances %llu insert %llu | expansions %llu | whole kernel %llu\n",
           stats[ST_PH_POP], stats[ST_PH_LIST], stats[ST_PH_DIST], stats[ST_PH_INSERT], stats[ST_PH_EXPANSIONS],
           stats[ST_PH_REST]);
+  fprintf(stderr, "[hny] short walk: visited wait %llu | lanes asked %llu accepted %llu expansions that accepted %llu pool scans %llu "
+          "expansions with nothing new %llu\n", stats[ST_PH_VIS], stats[ST_PH_NASK], stats[ST_PH_NACC], stats[ST_PH_NMERGE],
+          stats[ST_PH_NPOOL], stats[ST_PH_NONEW]);
 #endif
   if (getenv("HNY_DEBUG_COUNTS"))
     fprintf(stderr, "[hny] expansions %llu accepted %llu notfull %llu evals_walk %llu\n", stats[9], stats[10], stats[11],

@@ -36,7 +36,10 @@ enum {
   ST_ERR_GAPS_OVERFLOW = 8,
 #ifdef HNY_PHASE_CLOCKS // diagnostic build (HNY_CFLAGS=-DHNY_PHASE_CLOCKS): wave cycles per walk phase
   ST_PH_POP = 16, ST_PH_LIST = 17, ST_PH_DIST = 18, ST_PH_INSERT = 19, ST_PH_EXPANSIONS = 20, ST_PH_REST = 21,
-  ST_COUNT = 24
+  // walk_layer_short only: the visited round trip apart from the list fetch; lanes that asked the visited set,
+  // accepted keys, expansions that accepted any, tie-pool scans, expansions with nothing new
+  ST_PH_VIS = 22, ST_PH_NASK = 23, ST_PH_NACC = 24, ST_PH_NMERGE = 25, ST_PH_NPOOL = 26, ST_PH_NONEW = 27,
+  ST_COUNT = 32
 #else
   ST_COUNT = 16
 #endif
@@ -129,6 +132,9 @@ struct WalkArgs {
   u32 force_pool;    // test hook (HNY_POOL_FORCE_RETRY=n): treat every member with m % n == 0 as overflowed
   u32 pool_flag;     // reader mode: a query whose tie pool overflowed reports cand_n = 0xFFFFFFFE (the host
                      // repeats it on the heap-queue searcher) instead of counting an error
+  // short-row build walks (walk_layer_short): LDS visited table of vis_buckets x 4 x 16-bit remainders, 0 = none
+  // (VisB in hny_kernels.hip); vis_magic = floor(2^40 / vis_buckets) + 1, vis_smask = 2^k - 1 >= n - 1
+  u32 vis_buckets, vis_magic, vis_smask;
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,

@@ -654,7 +654,7 @@ struct Beam {
   bool dropped;   // some evicted ordinary candidate with bits > res.max is still in `candidates`
   u32 pool_over, err;
 #ifdef HNY_PHASE_CLOCKS
-  u64 ph[5], ph_t; // cycles in pop / list+visited / distances / insert, expansions; last stamp
+  u64 ph[12], ph_t; // cycles in pop / list+visited / distances / insert, expansions (5..10: walk_layer_short's extras); last stamp
 #endif
 };
 #ifdef HNY_PHASE_CLOCKS
@@ -1363,6 +1363,95 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 //     serves the expansion;
 //   * lane-conditional LDS traffic is predicated by address (a dump slot) instead of by exec mask.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Visited set of a SHORT-row walk: a bucketized table of 16-bit remainders in LDS.
+// What bounds the short-row walk is not bytes and not instruction issue but the number of RETURNING
+// GLOBAL ATOMICS: one atomicOr on the wave's HBM bitset per neighbour looked at — 10.7 G of them in a C5
+// build (21 per expansion), and one MI355X sustains ~18 G random returning atomics per second on bitsets
+// of this size whatever the number of waves (scripts/micro/random_access_roof.hip; plain random loads:
+// ~55 G/s): 10.7 / 18 = the 0.59 s that the walk takes.  An open-addressing table of full 32-bit ids
+// large enough for the ~1 150 ids a walk marks costs the LDS that occupancy needs (round 2: slower at
+// every size).  So: the dense slot id goes through a bijection of [0, 2^k) (multiplication by an odd
+// constant mod 2^k >= n), the result splits into bucket = sid mod nb and remainder = sid div nb < 65 535,
+// and the bucket — ONE 8-byte LDS word — holds up to four remainders + 1 (0 = empty).  Bucket and remainder
+// identify the id exactly; a lookup is one ds_read_b64, an insertion one 64-bit compare-and-swap on the
+// bucket (a lane that loses the swap to a neighbour of the same bucket looks again).  640 buckets = 5 KB
+// per wave keep 20 waves per CU resident and hold 2 560 ids; an id whose bucket is full (a few per cent of
+// the insertions at ~1 150 ids) lives in the HBM bitset as before — membership is decided by "bucket full",
+// which never reverts during a walk, so the two levels cannot disagree.
+// ---------------------------------------------------------------------------------------------
+struct VisB {
+  u64 *tb;    // LDS: nb buckets x 4 x u16; null = bitset only
+  u32 nb;     // buckets
+  u32 magic;  // floor(2^40 / nb) + 1: sid div nb == (sid * magic) >> 40 for sid < 2^28
+  u32 smask;  // 2^k - 1
+};
+#define HNY_VISB_MUL 0x9E3779B1u
+
+__device__ __forceinline__ void visb_clear(const VisB &v) {
+  if (!v.tb) return;
+  float4 *t4 = reinterpret_cast<float4 *>(v.tb);
+  for (u32 i = HNY_LANE; i < v.nb / 2u; i += 64) t4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  WSYNC();
+}
+
+// mark ids (one per lane, `valid` lanes) visited; returns whether this lane's id was new (of two lanes with
+// the same id exactly one is told so).  `vis` = the bitset level (overflow), logged for its clear.
+__device__ __forceinline__ bool visb_insert(const VisB &v, Visited &vis, u32 id, bool valid) {
+  const u64 lt = (1ull << HNY_LANE) - 1ull;
+  bool isnew = false, over = valid;
+  if (v.tb) { // wave-uniform
+    const u32 sid = (id * HNY_VISB_MUL) & v.smask;
+    const u32 q = (u32)(((u64)sid * (u64)v.magic) >> 40);
+    const u32 bk = sid - q * v.nb;
+    const u64 rem4 = (u64)(q + 1u) * 0x0001000100010001ull;
+    const u64 ones = 0x0001000100010001ull, tops = 0x8000800080008000ull;
+    u64 cur = v.tb[bk]; // (lanes without an id read some bucket too: no exec juggling)
+    bool pending = valid;
+    over = false;
+    while (__ballot(pending)) {
+      const u64 x = cur ^ rem4;                       // a half equal to the remainder becomes 0
+      const bool found = ((x - ones) & ~x & tops) != 0ull;
+      const u64 z = (cur - ones) & ~cur & tops;       // lowest set bit: the first empty half
+      if (pending && !found && z != 0ull) {
+        const int sh = (__ffsll((long long)z) - 1) & 0x30; // 0, 16, 32, 48
+        const u64 want = cur | ((u64)(q + 1u) << sh);
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&v.tb[bk]), (unsigned long long)cur,
+                                  (unsigned long long)want);
+        if (old == cur) {
+          isnew = true;
+          pending = false;
+        } else {
+          cur = old; // a neighbour of the same bucket got there first: look again
+        }
+      } else if (pending) {
+        over = !found; // full and not in it: the bitset decides
+        pending = false;
+      }
+    }
+  }
+  const u64 om = __ballot(over);
+  if (om) { // wave-uniform; without a table: every valid lane
+    bool onew = false;
+    if (over) {
+      const u32 b = 1u << (id & 31);
+      onew = !(atomicOr(&vis.bits[id >> 5], b) & b);
+    }
+    const u64 nm = __ballot(onew);
+    const int n_log = __popcll(nm);
+    if (n_log) {
+      if (vis.log_len + (u32)n_log <= vis.log_cap) {
+        if (onew) vis.vlog[vis.log_len + (u32)__popcll(nm & lt)] = id;
+      } else {
+        vis.log_over = true;
+      }
+      vis.log_len += (u32)n_log;
+    }
+    isnew = isnew || onew;
+  }
+  return isnew;
+}
+
 // distances of rows ids[k0 .. k0 + 16) (as far as they are < n) to the query: the lane with (t & 3) == 0 of
 // lane group `sub` returns row ri = k0 + 8 * (t >> 2) + sub (wave order of an LPRO-lane row group, computed
 // by 8 lanes exactly as dist_rows_narrow does; LPRO == 8 is the plain 8-lane butterfly)
@@ -1433,7 +1522,7 @@ __device__ __forceinline__ u32 row_shr(u32 v) {
 template <int LPRO>
 __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4 (&q)[LPRO / 8], float qn, u32 layer,
                                                  int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
-                                                 u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
+                                                 const VisB &vb, u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
                                                  BeamR<2> &rb) {
   const int ln = HNY_LANE, t = ln & 7;
   const u64 lt = (1ull << ln) - 1ull;
@@ -1447,9 +1536,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
   {
     const int ne = n_eps; // <= 64 here
     u32 id = eps[ln < ne ? ln : 0];
-    bool isnew = visited_insert(vis, id, ln < ne);
-    u64 nmask = __ballot(isnew);
-    visited_log(vis, id, isnew, nmask, __popcll(nmask & lt));
+    (void)visb_insert(vb, vis, id, ln < ne);
     nb_ids[ln] = id;
     WSYNC();
     for (int k0 = 0; k0 < ne; k0 += 16) {
@@ -1503,6 +1590,9 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     // not closer; weird entries (sign bit / NaN) sort behind every ordinary distance.
     if (s.pool_len > 0 && (!have_a || s.n_weird > 0 || d0 >= s.tie_bits)) {
       static_assert(HNY_POOL_CAP == 128, "two pool entries per lane");
+#ifdef HNY_PHASE_CLOCKS
+      s.ph[9]++;
+#endif
       const bool h0 = ln < s.pool_len, h1 = ln + 64 < s.pool_len;
       const u64 k0 = s.pool[ln], k1 = s.pool[ln + 64];
       const u64 p0 = h0 ? ((k0 & 0xFFFFFFFF00000000ull) | (u64)(~(u32)(k0 & 0xFFFFFFFFull))) : ~0ull;
@@ -1543,24 +1633,18 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     const u32 *nl = nbr_ids(g, layer, cslot, cap);
     u32 id = nl[(u32)ln < cap ? (u32)ln : cap - 1u];
     const bool valid = (u32)ln < cap && id != HNY_SENT;
-    bool isnew = false;
-    if (valid) {
-      const u32 b = 1u << (id & 31);
-      isnew = !(atomicOr(&vis.bits[id >> 5], b) & b);
-    }
+#ifdef HNY_PHASE_CLOCKS
+    s.ph[6] += (u64)__popcll(__ballot(valid)); // (the ballot needs the ids: the list fetch ends here)
+    PH_STAMP(s, 1);
+#endif
+    bool isnew = visb_insert(vb, vis, id, valid);
     u64 nmask = __ballot(isnew);
     if (!nmask) {
-      PH_STAMP(s, 1);
+#ifdef HNY_PHASE_CLOCKS
+      s.ph[10]++;
+#endif
+      PH_STAMP(s, 5);
       continue;
-    }
-    {
-      const int n_log = __popcll(nmask);
-      if (vis.log_len + (u32)n_log <= vis.log_cap) {
-        if (isnew) vis.vlog[vis.log_len + (u32)__popcll(nmask & lt)] = id;
-      } else {
-        vis.log_over = true;
-      }
-      vis.log_len += (u32)n_log;
     }
     if (len < ef) {
       // duplicates inside one list (add_link never dedups, hnsw.rs:521): while res is not full
@@ -1583,7 +1667,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     const int n_new = __popcll(nmask);
     nb_ids[isnew ? __popcll(nmask & lt) : 64 + ln] = id; // (64 + ln: the dump words)
     WSYNC();
-    PH_STAMP(s, 1);
+    PH_STAMP(s, 5);
     // ---- :503-512 score the new points, keep those that enter res
     int room = ef - len;
     if (room < 0) room = 0;
@@ -1612,6 +1696,10 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     PH_STAMP(s, 2);
     u64 amask = __ballot(acc != 0u);
     if (!amask) continue;
+#ifdef HNY_PHASE_CLOCKS
+    s.ph[7] += (u64)__popcll(amask);
+    s.ph[8]++;
+#endif
     if (__popcll(amask) >= HNY_RB_MERGE_MIN && HNY_RB_MERGE) { // one key: the plain insert is cheaper
       beam_merge_rb<2>(s, rb, acc != 0u, ((u64)khi << 32) | (u64)klo, ef);
       amask = 0ull;
@@ -1676,7 +1764,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
 
   Beam s;
 #ifdef HNY_PHASE_CLOCKS
-  for (int i = 0; i < 5; i++) s.ph[i] = 0;
+  for (int i = 0; i < 12; i++) s.ph[i] = 0;
   s.ph_t = 0;
   const u64 ph_kernel_t0 = __builtin_readcyclecounter();
 #endif
@@ -1700,10 +1788,28 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   // 0.69-0.75, C4-like 0.88 against 0.88: no gain, DESIGN.md §5 "Short rows")
   // rows <= 1 KB never get an LDS table (the host passes vis_slots = 0 for them): say so at compile
   // time in the specialised kernels, so that the table's code and its six wave-uniform fields go
+#ifdef HNY_SHORT_TAB // experiment: the LDS visited table for short rows too (the host passes vis_slots)
+  constexpr bool NO_TAB = false;
+#else
   constexpr bool NO_TAB = SP != 0 && NCH == 1;
+#endif
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u),
                NO_TAB ? 0u : a.vis_slots);
+  VisB vb;
+  vb.tb = nullptr;
+  vb.nb = 0;
+  vb.magic = 0;
+  vb.smask = 0;
+  if constexpr (SHORT && !RM) {
+    if (a.vis_buckets) { // (behind eps; NO_TAB kernels have no other table there)
+      vb.tb = reinterpret_cast<u64 *>(eps + 64);
+      vb.nb = a.vis_buckets;
+      vb.magic = a.vis_magic;
+      vb.smask = a.vis_smask;
+      visb_clear(vb);
+    }
+  }
   u64 evals = 0;
   u32 err_iter = 0, log_over_cnt = 0;
 
@@ -1792,7 +1898,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
       if constexpr (SHORT)
-        walk_layer_short<LPR>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids, nb_d, evals, err_iter, rb);
+        walk_layer_short<LPR>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
       else
         walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                      nb_d, evals, err_iter, qrow, rb);
@@ -1808,6 +1914,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       if (!a.reader_mode || layer == a.layer + 1) {
         if (vis.log_over) log_over_cnt++;
         visited_clear(vis);
+        visb_clear(vb);
       }
       WSYNC();
     }
@@ -1873,7 +1980,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
         if (ln == 0) eps[0] = slot;
         WSYNC();
         if constexpr (SHORT)
-          walk_layer_short<LPR>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, rb);
+          walk_layer_short<LPR>(g, q, qn, 0u, ef2, eps, 1, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
         else
           walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         if (total + s.res_len > (int)a.rcap) {
@@ -1920,6 +2027,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     if (ln == 0) a.cand_n[m] = (u32)total;
     if (vis.log_over) log_over_cnt++;
     visited_clear(vis);
+    visb_clear(vb);
   }
 #ifdef HNY_PHASE_CLOCKS
   if (ln == 0) {
@@ -1929,6 +2037,12 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
     atomicAdd(&g.stats[ST_PH_INSERT], s.ph[3]);
     atomicAdd(&g.stats[ST_PH_EXPANSIONS], s.ph[4]);
     atomicAdd(&g.stats[ST_PH_REST], __builtin_readcyclecounter() - ph_kernel_t0);
+    atomicAdd(&g.stats[ST_PH_VIS], s.ph[5]);
+    atomicAdd(&g.stats[ST_PH_NASK], s.ph[6]);
+    atomicAdd(&g.stats[ST_PH_NACC], s.ph[7]);
+    atomicAdd(&g.stats[ST_PH_NMERGE], s.ph[8]);
+    atomicAdd(&g.stats[ST_PH_NPOOL], s.ph[9]);
+    atomicAdd(&g.stats[ST_PH_NONEW], s.ph[10]);
   }
 #endif
   if (ln == 0) {
@@ -2123,7 +2237,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
 
   Beam s; // greedy descent through the upper layers: the ordinary (unfiltered) walk
 #ifdef HNY_PHASE_CLOCKS
-  for (int i = 0; i < 5; i++) s.ph[i] = 0;
+  for (int i = 0; i < 12; i++) s.ph[i] = 0;
   s.ph_t = 0;
 #endif
   s.res = res;
@@ -4298,7 +4412,8 @@ struct Hot {
   template <int L, int C>
   struct Walk {
     static hipError_t run(const GraphDev &g, const WalkArgs &a, int grid, hipStream_t st) {
-      size_t lds = hnyk_walk_lds_bytes(a.res_global ? 0u : a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4;
+      size_t lds = hnyk_walk_lds_bytes(a.res_global ? 0u : a.rcap, a.eps_cap) + (size_t)a.vis_slots * 4 +
+                   (size_t)a.vis_buckets * 8;
       if constexpr (SP == 0) {
         if (a.eps_cap > 64) {
           hipLaunchKernelGGL((k_walk<L, C, true, 0>), dim3(grid), dim3(64), lds, st, g, a);
