@@ -66,6 +66,10 @@
 namespace {
 
 __device__ __forceinline__ u32 fbits(float f) { return __float_as_uint(f); }
+// the wave's vote on a predicate as a 64-bit mask.  (HIP's __ballot takes an int: a bool that the compiler
+// holds as a lane mask is first turned into 0 / 1 per lane and compared with 0 again — two vector
+// instructions per vote, ~20 votes per expansion of a walk)
+__device__ __forceinline__ u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // SP = 0: general kernel.  SP = metric + 1: the kernel's private copy of GraphDev carries the
 // metric as a constant and has strict mode and the incremental branches switched off, so that
@@ -651,7 +655,7 @@ struct Beam {
   int res_len, pool_len, rcap;
   int n_weird;    // pool entries whose distance bits are not an ordinary non-negative float
   u32 tie_bits;   // distance bits shared by the ordinary pool entries (== bits of res.max)
-  bool dropped;   // some evicted ordinary candidate with bits > res.max is still in `candidates`
+  int dropped;    // some evicted ordinary candidate with bits > res.max is still in `candidates`
   u32 pool_over, err;
 #ifdef HNY_PHASE_CLOCKS
   u64 ph[12], ph_t; // cycles in pop / list+visited / distances / insert, expansions (5..10: walk_layer_short's extras); last stamp
@@ -697,7 +701,7 @@ __device__ __forceinline__ void settle(Beam &s) {
   s.pool_len = uni(s.pool_len);
   s.n_weird = uni(s.n_weird);
   s.tie_bits = uni(s.tie_bits);
-  s.dropped = uni((int)s.dropped) != 0;
+  s.dropped = uni(s.dropped);
   s.pool_over = uni(s.pool_over);
   s.err = uni(s.err);
 }
@@ -726,7 +730,7 @@ __device__ __forceinline__ void pool_drop_ties(Beam &s) {
   u64 a1 = ln + 64 < s.pool_len ? s.pool[ln + 64] : 0ull;
   bool k0 = ln < s.pool_len && weird_bits((u32)(a0 >> 32));
   bool k1 = ln + 64 < s.pool_len && weird_bits((u32)(a1 >> 32));
-  u64 m0 = __ballot(k0), m1 = __ballot(k1);
+  u64 m0 = ballot(k0), m1 = ballot(k1);
   u64 lt = (1ull << ln) - 1ull;
   WSYNC();
   if (k0) s.pool[__popcll(m0 & lt)] = a0;
@@ -758,7 +762,7 @@ __device__ __forceinline__ void beam_insert(Beam &s, u64 key, int ef) {
   for (int base = 0; base < len; base += 64) {
     int e = base + ln;
     bool lt = e < len && ((s.res[e] & ~1ull) < key);
-    pos += __popcll(__ballot(lt));
+    pos += __popcll(ballot(lt));
   }
   const bool evict = (len == ef);
   const u64 oldmax = len ? uni(s.res[len - 1]) : 0ull;
@@ -825,7 +829,7 @@ __device__ __forceinline__ void beam_insert_rb(Beam &s, BeamR<RC> &r, u64 key, i
   const int len = s.res_len;
   int pos = 0;
 #pragma unroll
-  for (int c = 0; c < RC; c++) pos += __popcll(__ballot(ln + 64 * c < len && (r.r[c] & ~1ull) < key));
+  for (int c = 0; c < RC; c++) pos += __popcll(ballot(ln + 64 * c < len && (r.r[c] & ~1ull) < key));
   const bool evict = (len == ef);
   const u64 oldmax = len ? rb_get<RC>(r, len - 1) : 0ull;
   if (evict && pos == len) { // the new entry is the max: pushed and popped at once
@@ -868,7 +872,7 @@ __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u
   const int ln = HNY_LANE;
   settle(s);
   const int len = s.res_len;
-  u64 m = __ballot(acc);
+  u64 m = ballot(acc);
   const int A = __popcll(m);
   u64 kc[RC];
   bool inr[RC];
@@ -889,7 +893,7 @@ __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u
 #pragma unroll
     for (int c = 0; c < RC; c++) {
       const bool l = inr[c] && kc[c] < ki; // keys are distinct (one slot, one key)
-      below += __popcll(__ballot(l));
+      below += __popcll(ballot(l));
       sh[c] += (inr[c] && !l) ? 1 : 0;
     }
     mypos += (acc && ki < key) ? 1 : 0;
@@ -931,17 +935,17 @@ __device__ __forceinline__ void beam_merge_rb(Beam &s, BeamR<RC> &r, bool acc, u
     const bool un = ev && !(x & 1ull); // already popped from `candidates`: nothing to keep
     const bool w = weird_bits(xb);
     const bool keep = un && (w || xb == nd);
-    if (__ballot(un && !w && xb != nd)) s.dropped = true;
-    const u64 pm = __ballot(keep);
+    if (ballot(un && !w && xb != nd)) s.dropped = true;
+    const u64 pm = ballot(keep);
     if (pm) {
-      if (__ballot(keep && !w)) s.tie_bits = nd;
+      if (ballot(keep && !w)) s.tie_bits = nd;
       int room = HNY_POOL_CAP - s.pool_len;
       if (room < 0) room = 0;
       const int rank = __popcll(pm & lt);
       const bool put = keep && rank < room;
       if (put) s.pool[s.pool_len + rank] = x & ~1ull;
       const int np = __popcll(pm), nput = np < room ? np : room;
-      s.n_weird += __popcll(__ballot(put && w));
+      s.n_weird += __popcll(ballot(put && w));
       s.pool_len += nput;
       s.pool_over += (u32)(np - nput);
       WSYNC();
@@ -974,11 +978,11 @@ struct Visited {
   u32 *bits;
   u32 *vlog;
   u32 bits_words, log_cap, log_len;
-  bool log_over;
+  int log_over;
   u32 *tab;       // LDS, `slots` entries, HNY_SENT = empty; null: bitset only
   u32 slots, count, limit;
-  bool spill;     // the table is closed for insertion: new ids go to the bitset
-  bool in_bits;   // the last visited_insert went to the bitset (its new ids must be logged)
+  int spill;      // the table is closed for insertion: new ids go to the bitset
+  int in_bits;    // the last visited_insert went to the bitset (its new ids must be logged)
 };
 
 __device__ __forceinline__ void visited_init(Visited &v, u32 *bits, u32 bits_words, u32 *vlog, u32 log_cap,
@@ -1052,7 +1056,7 @@ __device__ __forceinline__ bool visited_insert(Visited &v, u32 id, bool valid) {
       }
     }
     if (ins) {
-      v.count += (u32)__popcll(__ballot(isnew));
+      v.count += (u32)__popcll(ballot(isnew));
       if (v.count > v.limit) v.spill = true;
       v.in_bits = false;
       return isnew;
@@ -1094,10 +1098,10 @@ __device__ __forceinline__ void visited_flush(Visited &v) {
 
 __device__ __forceinline__ void settle(Visited &v) {
   v.log_len = uni(v.log_len);
-  v.log_over = uni((int)v.log_over) != 0;
+  v.log_over = uni(v.log_over);
   v.count = uni(v.count);
-  v.spill = uni((int)v.spill) != 0;
-  v.in_bits = uni((int)v.in_bits) != 0;
+  v.spill = uni(v.spill);
+  v.in_bits = uni(v.in_bits);
 }
 
 // One walk_layer call (hnsw.rs:460-518).  eps[0..n_eps) and all scratch in LDS.
@@ -1128,7 +1132,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     const int ne = BIG_EPS ? (n_eps - e0 < 64 ? n_eps - e0 : 64) : n_eps;
     u32 id = ln < ne ? eps[e0 + ln] : 0u;
     bool isnew = visited_insert(vis, id, ln < ne);
-    u64 nmask = __ballot(isnew);
+    u64 nmask = ballot(isnew);
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
     if (BIG_EPS) WSYNC();
     if (ln < ne) nb_ids[ln] = id;
@@ -1166,7 +1170,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 #pragma unroll
       for (int c = RCN - 1; c >= 0; c--) {
         un[c] = ln + 64 * c < len && !(rb.r[c] & 1ull);
-        const u64 mk = __ballot(un[c]);
+        const u64 mk = ballot(un[c]);
         if (mk) first_un = 64 * c + __ffsll((long long)mk) - 1; // the lowest chunk wins (descending loop)
       }
       dmax = (u32)(rb_get<RCN>(rb, len - 1) >> 32);
@@ -1175,7 +1179,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         const u32 d0 = (u32)(rb_get<RCN>(rb, first_un) >> 32);
 #pragma unroll
         for (int c = 0; c < RCN; c++) {
-          const u64 tk = __ballot(un[c] && (u32)(rb.r[c] >> 32) == d0);
+          const u64 tk = ballot(un[c] && (u32)(rb.r[c] >> 32) == d0);
           if (tk) last = 64 * c + 63 - __clzll((long long)tk); // the highest chunk wins
         }
         ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get<RCN>(rb, last) & 0xFFFFFFFEull));
@@ -1184,7 +1188,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
     for (int base = 0; base < s.res_len; base += 64) {
       int e = base + ln;
       bool un = e < s.res_len && !(s.res[e] & 1ull);
-      u64 mk = __ballot(un);
+      u64 mk = ballot(un);
       if (mk) {
         first_un = base + __ffsll((long long)mk) - 1;
         break;
@@ -1198,7 +1202,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       for (int base = first_un & ~63; base < s.res_len; base += 64) {
         int e = base + ln;
         bool ok = e >= first_un && e < s.res_len && (u32)(s.res[e] >> 32) == d0 && !(s.res[e] & 1ull);
-        u64 mk = __ballot(ok);
+        u64 mk = ballot(ok);
         if (mk) last = base + 63 - __clzll((long long)mk);
         int ce = base + 63 < s.res_len - 1 ? base + 63 : s.res_len - 1;
         if (uni((u32)(s.res[ce] >> 32)) != d0) break;
@@ -1221,8 +1225,8 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       const bool second = h1 && t1 < t0;
       const u64 mine = second ? t1 : t0;
       tp = uni(wave_min_u64(mine));
-      const int wl = __ffsll((long long)__ballot(h0 && mine == tp)) - 1; // h0: the lane holds an entry at all
-      pi = wl + (((__ballot(second) >> wl) & 1ull) ? 64 : 0);
+      const int wl = __ffsll((long long)ballot(h0 && mine == tp)) - 1; // h0: the lane holds an entry at all
+      pi = wl + (((ballot(second) >> wl) & 1ull) ? 64 : 0);
     }
     const bool have_a = first_un >= 0, have_p = pi >= 0;
     if (!have_a && !have_p) break; // candidates exhausted (or only dropped entries: they break)
@@ -1269,7 +1273,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       u32 id = (u32)ln < pcap ? nl[(PAGED ? c0 : 0u) + ln] : HNY_SENT;
       bool valid = id != HNY_SENT;
       bool isnew = visited_insert(vis, id, valid);
-      u64 nmask = __ballot(isnew);
+      u64 nmask = ballot(isnew);
       if (!nmask) {
         PH_STAMP(s, 1);
         continue;
@@ -1277,7 +1281,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
       if (g.incremental) { // MissingKey => the item was deleted: visited, but never scored (:498-502)
         isnew = isnew && g.has_vec[id] != 0;
-        nmask = __ballot(isnew);
+        nmask = ballot(isnew);
         if (!nmask) continue;
       }
       if (s.res_len < ef) {
@@ -1296,7 +1300,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
         }
         isnew = valid && anynew && firstj == ln;
         WSYNC();
-        nmask = __ballot(isnew);
+        nmask = ballot(isnew);
       }
       const int n_new = __popcll(nmask);
       const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
@@ -1314,7 +1318,7 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
       if (room < 0) room = 0;
       // :505 `res.len() < ef || dist < f_max` — the first `room` new points are taken regardless
       bool acc = ln < n_new && (ln < room || myd < fmax);
-      u64 amask = __ballot(acc);
+      u64 amask = ballot(acc);
       WSYNC();
       if constexpr (RB) {
         if (__popcll(amask) >= HNY_RB_MERGE_MIN && HNY_RB_MERGE) { // one key: the plain insert is cheaper
@@ -1404,25 +1408,30 @@ __device__ __forceinline__ bool visb_insert(const VisB &v, Visited &vis, u32 id,
     const u32 sid = (id * HNY_VISB_MUL) & v.smask;
     const u32 q = (u32)(((u64)sid * (u64)v.magic) >> 40);
     const u32 bk = sid - q * v.nb;
-    const u64 rem4 = (u64)(q + 1u) * 0x0001000100010001ull;
-    const u64 ones = 0x0001000100010001ull, tops = 0x8000800080008000ull;
-    u64 cur = v.tb[bk]; // (lanes without an id read some bucket too: no exec juggling)
+    const u32 r = q + 1u, r2 = r | (r << 16); // the remainder (+ 1) in both halves of a word
+    uint2 cur = reinterpret_cast<const uint2 *>(v.tb)[bk]; // (lanes without an id read some bucket too: no exec juggling)
     bool pending = valid;
     over = false;
-    while (__ballot(pending)) {
-      const u64 x = cur ^ rem4;                       // a half equal to the remainder becomes 0
-      const bool found = ((x - ones) & ~x & tops) != 0ull;
-      const u64 z = (cur - ones) & ~cur & tops;       // lowest set bit: the first empty half
-      if (pending && !found && z != 0ull) {
-        const int sh = (__ffsll((long long)z) - 1) & 0x30; // 0, 16, 32, 48
-        const u64 want = cur | ((u64)(q + 1u) << sh);
-        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&v.tb[bk]), (unsigned long long)cur,
-                                  (unsigned long long)want);
-        if (old == cur) {
+    while (ballot(pending)) {
+      // a 16-bit half of `cur` equal to r: the zero-half test of (cur ^ r2)
+      const u32 x0 = cur.x ^ r2, x1 = cur.y ^ r2;
+      const bool found = ((((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1)) & 0x80008000u) != 0u;
+      // halves fill up in order and are never emptied: the first empty one
+      const bool e0 = cur.x == 0u, e1 = (cur.x >> 16) == 0u, e2 = cur.y == 0u, e3 = (cur.y >> 16) == 0u;
+      if (pending && !found && e3) {
+        const u32 add = (e0 || (e2 && !e1)) ? r : (r << 16);
+        uint2 want;
+        want.x = cur.x | (e1 ? add : 0u);
+        want.y = cur.y | (e1 ? 0u : add);
+        const u64 c64 = ((u64)cur.y << 32) | cur.x, w64 = ((u64)want.y << 32) | want.x;
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&v.tb[bk]), (unsigned long long)c64,
+                                  (unsigned long long)w64);
+        if (old == c64) {
           isnew = true;
           pending = false;
-        } else {
-          cur = old; // a neighbour of the same bucket got there first: look again
+        } else { // a neighbour of the same bucket got there first: look again
+          cur.x = (u32)old;
+          cur.y = (u32)(old >> 32);
         }
       } else if (pending) {
         over = !found; // full and not in it: the bitset decides
@@ -1430,14 +1439,14 @@ __device__ __forceinline__ bool visb_insert(const VisB &v, Visited &vis, u32 id,
       }
     }
   }
-  const u64 om = __ballot(over);
+  const u64 om = ballot(over);
   if (om) { // wave-uniform; without a table: every valid lane
     bool onew = false;
     if (over) {
       const u32 b = 1u << (id & 31);
       onew = !(atomicOr(&vis.bits[id >> 5], b) & b);
     }
-    const u64 nm = __ballot(onew);
+    const u64 nm = ballot(onew);
     const int n_log = __popcll(nm);
     if (n_log) {
       if (vis.log_len + (u32)n_log <= vis.log_cap) {
@@ -1570,7 +1579,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     // (BinaryHeap<(Reverse<OrderedFloat>, ItemId)>, :469, :483-488)
     const int len = s.res_len;
     const bool un0 = ln < len && !(rb.r[0] & 1ull), un1 = ln + 64 < len && !(rb.r[1] & 1ull);
-    const u64 m0 = __ballot(un0), m1 = __ballot(un1);
+    const u64 m0 = ballot(un0), m1 = ballot(un1);
     const u32 dmax = (u32)(rb_get<2>(rb, len - 1) >> 32);
     const bool have_a = (m0 | m1) != 0ull;
     int last = -1;
@@ -1579,7 +1588,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     if (have_a) { // pop-order key: distance bits ascending, then id DESCENDING
       const int first_un = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
       d0 = (u32)(rb_get<2>(rb, first_un) >> 32);
-      const u64 t0 = __ballot(un0 && (u32)(rb.r[0] >> 32) == d0), t1 = __ballot(un1 && (u32)(rb.r[1] >> 32) == d0);
+      const u64 t0 = ballot(un0 && (u32)(rb.r[0] >> 32) == d0), t1 = ballot(un1 && (u32)(rb.r[1] >> 32) == d0);
       last = t1 ? 64 + 63 - __clzll((long long)t1) : 63 - __clzll((long long)t0);
       ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get<2>(rb, last) & 0xFFFFFFFEull));
     }
@@ -1600,8 +1609,8 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
       const bool second = h1 && p1 < p0;
       const u64 mine = second ? p1 : p0;
       tp = uni(wave_min_u64(mine));
-      const int wl = __ffsll((long long)__ballot(h0 && mine == tp)) - 1; // h0: the lane holds an entry at all
-      pi = wl + (((__ballot(second) >> wl) & 1ull) ? 64 : 0);
+      const int wl = __ffsll((long long)ballot(h0 && mine == tp)) - 1; // h0: the lane holds an entry at all
+      pi = wl + (((ballot(second) >> wl) & 1ull) ? 64 : 0);
     }
     const bool have_p = pi >= 0;
     if (!have_a && !have_p) break; // candidates exhausted (or only dropped entries: they break)
@@ -1634,11 +1643,11 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     u32 id = nl[(u32)ln < cap ? (u32)ln : cap - 1u];
     const bool valid = (u32)ln < cap && id != HNY_SENT;
 #ifdef HNY_PHASE_CLOCKS
-    s.ph[6] += (u64)__popcll(__ballot(valid)); // (the ballot needs the ids: the list fetch ends here)
+    s.ph[6] += (u64)__popcll(ballot(valid)); // (the ballot needs the ids: the list fetch ends here)
     PH_STAMP(s, 1);
 #endif
     bool isnew = visb_insert(vb, vis, id, valid);
-    u64 nmask = __ballot(isnew);
+    u64 nmask = ballot(isnew);
     if (!nmask) {
 #ifdef HNY_PHASE_CLOCKS
       s.ph[10]++;
@@ -1662,7 +1671,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
       }
       isnew = valid && anynew && firstj == ln;
       WSYNC();
-      nmask = uni64(__ballot(isnew));
+      nmask = uni64(ballot(isnew));
     }
     const int n_new = __popcll(nmask);
     nb_ids[isnew ? __popcll(nmask & lt) : 64 + ln] = id; // (64 + ln: the dump words)
@@ -1694,7 +1703,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
 #undef HNY_SHORT_CHUNK
     evals += (u64)n_new;
     PH_STAMP(s, 2);
-    u64 amask = __ballot(acc != 0u);
+    u64 amask = ballot(acc != 0u);
     if (!amask) continue;
 #ifdef HNY_PHASE_CLOCKS
     s.ph[7] += (u64)__popcll(amask);
@@ -1966,7 +1975,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
           if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
           if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
         }
-        const u64 mk = __ballot(unv != 0u);
+        const u64 mk = ballot(unv != 0u);
         if (!mk) {
           pos = (wbase + 64u) << 5;
           continue;
@@ -2099,7 +2108,7 @@ __device__ __forceinline__ void qheap_pop(QHeap &Q) { // Q.size > 0
     const u64 ck = c < Q.size ? Q.h[c] : ~0ull;
     const u64 mn = wave_min_u64(ck);
     if (mn >= key) break;
-    const int wl = __ffsll((long long)__ballot(ck == mn)) - 1; // keys are unique
+    const int wl = __ffsll((long long)ballot(ck == mn)) - 1; // keys are unique
     if (ln == 0) Q.h[i] = mn;
     if (i == 0) Q.top = mn;
     i = base + (u32)wl;
@@ -2117,7 +2126,7 @@ __device__ __forceinline__ void sorted_insert(u64 *res, int &len, u64 key, int e
   for (int base = 0; base < len; base += 64) {
     int e = base + ln;
     bool lt = e < len && res[e] < key;
-    pos += __popcll(__ballot(lt));
+    pos += __popcll(ballot(lt));
   }
   const bool evict = (len == ef);
   if (evict && pos == len) return; // the new entry is the max: pushed and popped at once
@@ -2162,7 +2171,7 @@ __device__ int visit_filtered(const GraphDev &g, const float4 (&q)[NCH], float q
     const int ne = n_eps - e0 < 64 ? n_eps - e0 : 64;
     u32 id = ln < ne ? eps[e0 + ln] : 0u;
     bool isnew = visited_insert(vis, id, ln < ne);
-    u64 nmask = __ballot(isnew);
+    u64 nmask = ballot(isnew);
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
     WSYNC();
     if (ln < ne) nb_ids[ln] = id;
@@ -2196,12 +2205,12 @@ __device__ int visit_filtered(const GraphDev &g, const float4 (&q)[NCH], float q
       u32 id = c0 + (u32)ln < cap ? nl[c0 + ln] : HNY_SENT;
       bool valid = id != HNY_SENT;
       bool isnew = visited_insert(vis, id, valid); // path.insert(point), :347
-      u64 nmask = __ballot(isnew);
+      u64 nmask = ballot(isnew);
       if (!nmask) continue;
       visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
       if (g.incremental) {
         isnew = isnew && g.has_vec[id] != 0;
-        nmask = __ballot(isnew);
+        nmask = ballot(isnew);
         if (!nmask) continue;
       }
       const int n_new = __popcll(nmask);
@@ -2329,7 +2338,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_filtered(GraphDev g, NnsArgs a) {
             if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
             if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
           }
-          const u64 mk = __ballot(unv != 0u);
+          const u64 mk = ballot(unv != 0u);
           if (!mk) {
             pos = (wbase + 64u) << 5;
             continue;
@@ -2411,7 +2420,7 @@ __device__ int walk_layer_heap(const GraphDev &g, const float4 (&q)[NCH], float 
     const int ne = n_eps - e0 < 64 ? n_eps - e0 : 64;
     u32 id = ln < ne ? eps[e0 + ln] : 0u;
     bool isnew = visited_insert(vis, id, ln < ne);
-    u64 nmask = __ballot(isnew);
+    u64 nmask = ballot(isnew);
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
     WSYNC();
     if (ln < ne) nb_ids[ln] = id;
@@ -2444,7 +2453,7 @@ __device__ int walk_layer_heap(const GraphDev &g, const float4 (&q)[NCH], float 
         u32 id = (u32)ln < pcap ? nl[c0 + ln] : HNY_SENT;
         const bool valid = id != HNY_SENT;
         bool isnew = visited_insert(vis, id, valid); // :493
-        u64 nmask = __ballot(isnew);
+        u64 nmask = ballot(isnew);
         if (!nmask) continue;
         visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
         // the same id twice in one list (add_link never dedups, :521): the FIRST occurrence is the one the
@@ -2464,7 +2473,7 @@ __device__ int walk_layer_heap(const GraphDev &g, const float4 (&q)[NCH], float 
         isnew = valid && anynew && firstj == ln;
         if (g.incremental) isnew = isnew && g.has_vec[id] != 0; // MissingKey: visited, never scored (:498-502)
         WSYNC();
-        nmask = __ballot(isnew);
+        nmask = ballot(isnew);
         if (!nmask) continue;
         const int n_new = __popcll(nmask);
         const int rank = __popcll(nmask & ((1ull << ln) - 1ull));
@@ -2613,7 +2622,7 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
               if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
               if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
             }
-            const u64 mk = __ballot(unv != 0u);
+            const u64 mk = ballot(unv != 0u);
             if (!mk) {
               pos = (wbase + 64u) << 5;
               continue;
@@ -2684,7 +2693,7 @@ __device__ int visit_heap(const GraphDev &g, const float4 (&q)[NCH], float qn, i
     const int ne = n_eps - e0 < 64 ? n_eps - e0 : 64;
     u32 id = ln < ne ? eps[e0 + ln] : 0u;
     bool isnew = visited_insert(vis, id, ln < ne);
-    u64 nmask = __ballot(isnew);
+    u64 nmask = ballot(isnew);
     visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
     WSYNC();
     if (ln < ne) nb_ids[ln] = id;
@@ -2713,12 +2722,12 @@ __device__ int visit_heap(const GraphDev &g, const float4 (&q)[NCH], float qn, i
         u32 id = c0 + (u32)ln < cap ? nl[c0 + ln] : HNY_SENT;
         bool valid = id != HNY_SENT;
         bool isnew = visited_insert(vis, id, valid); // path.insert(point), :347
-        u64 nmask = __ballot(isnew);
+        u64 nmask = ballot(isnew);
         if (!nmask) continue;
         visited_log(vis, id, isnew, nmask, __popcll(nmask & ((1ull << ln) - 1ull)));
         if (g.incremental) {
           isnew = isnew && g.has_vec[id] != 0;
-          nmask = __ballot(isnew);
+          nmask = ballot(isnew);
           if (!nmask) continue;
         }
         const int n_new = __popcll(nmask);
@@ -2846,7 +2855,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_heap(GraphDev g, NnsArgs a) {
               if (ln == 0 && (pos & 31u)) unv &= ~((1u << (pos & 31u)) - 1u);
               if (widx == nwords - 1 && (g.n & 31u)) unv &= (1u << (g.n & 31u)) - 1u;
             }
-            const u64 mk = __ballot(unv != 0u);
+            const u64 mk = ballot(unv != 0u);
             if (!mk) {
               pos = (wbase + 64u) << 5;
               continue;
@@ -2946,7 +2955,7 @@ __global__ __launch_bounds__(64, 4) void k_nns_linear(GraphDev g, NnsArgs a) {
       WSYNC();
       const u64 key = ln < nc ? (((u64)fbits(nb_d[ln]) << 32) | nb_ids[ln]) : ~0ull;
       const u64 cur_max = (res_len == (int)a.k && res_len) ? uni(res[res_len - 1]) : ~0ull;
-      u64 want = __ballot(ln < nc && (res_len < (int)a.k || key < cur_max));
+      u64 want = ballot(ln < nc && (res_len < (int)a.k || key < cur_max));
       while (want) {
         const int r = __ffsll((long long)want) - 1;
         want &= want - 1ull;
@@ -2997,7 +3006,7 @@ __device__ int wave_prune(const GraphDev &g, const u64 *list, int n, int cap, u6
         float da = tmp_d[ln] * g.alpha; // :585 OrderedFloat(d * alpha) < dist_to_query
         v = fbits(da) < cdb;
       }
-      viol = __ballot(v) != 0ull;
+      viol = ballot(v) != 0ull;
       WSYNC();
     }
     if (!viol) {
@@ -3149,7 +3158,7 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
         else
           d = finalize_f32(g, fold4<LPR, float>(pf[0], pf[1], pf[2], pf[3]), cn, rn);
         const float da = d * g.alpha; // hnsw.rs:585
-        viol = __ballot(on && fbits(da) < cdb) != 0ull;
+        viol = ballot(on && fbits(da) < cdb) != 0ull;
         evals += (u64)((gend - g0) * RPG); // wave-uniform; lane 0's copy is the one that is added up
       };
       int g0 = 0;
@@ -3201,7 +3210,7 @@ __device__ __forceinline__ int wg_prune(const GraphDev &g, const u64 *list, int 
             const bool hit = sub == 0 && jm < w && ((svmask >> jm) & 1u) != 0u && fbits(da) < cdb;
 #pragma unroll
             for (int j = 0; j < 4; j++)
-              if (__ballot(hit && j4 == j) != 0ull) vm |= 1u << (q4 * 4 + j);
+              if (ballot(hit && j4 == j) != 0ull) vm |= 1u << (q4 * 4 + j);
           }
         }
         evals += (u64)w;
@@ -3405,7 +3414,7 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, const u64 *list,
     // (2) against S as it stands
     bool viol = false;
     for (int j = 0; j < s_len; j++) {
-      const u64 open = __ballot(have && !viol);
+      const u64 open = ballot(have && !viol);
       if (!open) break;
       float4 r[NQ];
       if (j < SL) load8_lds(stage + (size_t)j * g.row_stride, r);
@@ -3415,7 +3424,7 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, const u64 *list,
       evals += (u64)(__popcll(open) >> 3);
     }
     // (3) the survivors, in candidate order
-    u64 sv = __ballot(have && !viol && t == 0);
+    u64 sv = ballot(have && !viol && t == 0);
     while (sv && s_len < cap) {
       const int l1 = __ffsll((long long)sv) - 1, g1 = l1 >> 3;
       sv &= sv - 1ull;
@@ -3441,7 +3450,7 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, const u64 *list,
         const float d = dist8<LPRO>(g, c, r, cn, s_norm[s_len]);
         const bool out = fbits(d * g.alpha) < cdb;
         evals += (u64)__popcll(sv);
-        sv &= ~__ballot(out && t == 0);
+        sv &= ~ballot(out && t == 0);
         WSYNC(); // newrow is rewritten by the next selection
       }
       s_len++;
@@ -3977,7 +3986,7 @@ __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u
         if (xl) {
           const u32 y = (u32)ln < c2 ? xl[ln] : HNY_SENT;
           const bool v = y != HNY_SENT;
-          const u64 m = __ballot(v);
+          const u64 m = ballot(v);
           const int pos = nu + __popcll(m & ((1ull << ln) - 1ull));
           if (v && pos < MAXU) cand[pos] = y;
           nu += __popcll(m);
@@ -4010,7 +4019,7 @@ __global__ __launch_bounds__(64) void k_fill_gaps(GraphDev g, const u64 *recs, u
         }
         bm[pos] = v;
       }
-      nb += __popcll(__ballot(kept));
+      nb += __popcll(ballot(kept));
     }
     WSYNC();
     const u32 oi = ln < cnt ? ids[ln] : HNY_SENT;
@@ -4292,7 +4301,7 @@ __global__ __launch_bounds__(64) void k_finalize_lists(u32 *ids, u32 *cnt_out, u
         for (u32 j = 0; j < cap; j++) pos += (fst[j] != 0u && sh[j] < v) ? 1 : 0;
         row[pos] = v; // rank among the first occurrences: every slot was cleared above
       }
-      kept += (u32)__popcll(__ballot(first));
+      kept += (u32)__popcll(ballot(first));
     }
     if (ln == 0) cnt_out[li] = kept;
     WSYNC();
@@ -4371,7 +4380,7 @@ __global__ __launch_bounds__(64) void k_quantize(const float *v, u32 dim, u64 n,
       const u32 bits = __float_as_uint(v[vi * dim + d]);
       one = binary_codec ? (bits < 0x80000000u && bits > 0u) : (bits >> 31) == 0u;
     }
-    const u64 word = __ballot(one);
+    const u64 word = ballot(one);
     if (ln == 0) out[w] = word;
   }
 }
