@@ -3,7 +3,7 @@
 
 The regular -m gpu suite checks the full-size builds through size-independent properties (the oracle
 needs minutes per config on the box's host cores); this script does the whole comparison once per
-round and writes gpurun_out/r03_full_size_graph_parity.json (-> profiles/):  same data as bench.py, same levels, same
+round and writes gpurun_out/r04_full_size_graph_parity.json (-> profiles/):  same data as bench.py, same levels, same
 batch schedule, oracle in the wave summation order on every host core -> identical records
 (rec_item, rec_layer, offsets, neighbours), entry points, link count and walk-evaluation count.
 
@@ -46,10 +46,18 @@ def main():
     heartbeat()
     dev = torch.device("cuda", 0)
     cores = os.cpu_count() or 1
-    # (on the GPU box only gpurun_out/ travels back: copy the file to profiles/ afterwards)
-    out_path = os.environ.get("OUT", os.path.join(ROOT, "gpurun_out", "r03_full_size_graph_parity.json"))
+    # On the GPU box only gpurun_out/ travels back, and it starts empty there: a run of SOME configs starts from
+    # the committed file (profiles/ travels with the snapshot) and adds to it, so copying the result back to
+    # profiles/ never drops the entries of an earlier call (round 3 lost three of four that way).
+    name = "r04_full_size_graph_parity.json"
+    out_path = os.environ.get("OUT", os.path.join(ROOT, "gpurun_out", name))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    out = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    out = {}
+    for src in (os.path.join(ROOT, "profiles", name), out_path):
+        if os.path.exists(src):
+            out.update(json.load(open(src)))
+    import hashlib
+    ksha = hashlib.sha1(open(os.path.join(ROOT, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb").read()).hexdigest()
     for name in which:
         mname, n, dim, M, ef = CFG[name]
         metric = {"cosine": H.COSINE, "euclidean": H.EUCLIDEAN, "hamming": H.HAMMING}[mname]
@@ -74,7 +82,8 @@ def main():
                "graphs_identical": bool(same), "records": int(len(g.rec_item)), "links": int(len(g.nbrs)),
                "n_links_added": [int(g.n_links_added), int(o.n_links_added)],
                "n_evals_walk": [int(g.n_evals_walk), int(o.n_evals_walk)],
-               "gpu_build_incl_upload_s": round(t_gpu, 2), "oracle_build_s": round(t_cpu, 1), "oracle_threads": cores}
+               "gpu_build_incl_upload_s": round(t_gpu, 2), "oracle_build_s": round(t_cpu, 1), "oracle_threads": cores,
+               "kernel_source_sha1": ksha}
         print(json.dumps(res), flush=True)
         out[name] = res
         json.dump(out, open(out_path, "w"), indent=1)

@@ -28,8 +28,10 @@ def orc():
 
 
 def draw_levels(n, M, seed):
-    """Levels with the reference's distribution P(l) = M^-l (1 - 1/M) (hnsw.rs:94-119);
-    the reference's ChaCha12 stream is not restated, so levels are an input everywhere."""
+    """Levels with the reference's distribution P(l) = M^-l (1 - 1/M) (hnsw.rs:94-119), from numpy's
+    generator: most tests take levels as an INPUT (product and oracle get the same array).  The reference's
+    own stream — rand 0.8.5 StdRng = ChaCha12 + WeightedIndex<f32> — is restated in product and oracle
+    (hannoy_amd.draw_levels, orc.draw_levels) and pinned by KAT-1/5/9 (tests/test_oracle_kat.py)."""
     rng = np.random.default_rng(seed)
     u = rng.random(n)
     lv = np.floor(-np.log(1.0 - u) / np.log(M)).astype(np.int64)

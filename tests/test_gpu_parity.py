@@ -581,6 +581,38 @@ def test_full_size_other_baseline_configs(orc, hny, cfg):
     assert int(cnt.min()) == 10 and np.all(np.diff(dists, axis=1) >= 0)  # drain_asc, k hits each
 
 
+MID_SIZE = {"C2": ("cosine", 200_000, 768, 16, 100), "C3": ("euclidean", 100_000, 768, 32, 200),
+            "C4": ("cosine", 500_000, 128, 16, 100), "C5": ("hamming", 500_000, 1024, 16, 64)}
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
+def test_mid_size_build_equals_oracle(orc, hny, cfg):
+    """Every BASELINE kernel family at a size where the production paths are the ones that run — bench.py's own
+    generator, ChaCha12-drawn levels, the DEFAULT schedule (65 536-member batches, locality order, XCD-tiled
+    queue on long rows, register beam, k_prune_n8 / k_apply_n8 and the LDS visited table on short rows) — and the
+    oracle still finishes in seconds on the box's host threads: the graph equals the oracle's record for record
+    and edge for edge, with the same link and walk-evaluation counts.  (scripts/full_size_graph_parity.py does
+    the same at the BASELINE sizes, minutes of oracle per config: profiles/r04_full_size_graph_parity.json.)"""
+    import torch
+    from bench import gen_data
+    mname, n, dim, M, ef = MID_SIZE[cfg]
+    metric = {"cosine": hny.COSINE, "euclidean": hny.EUCLIDEAN, "hamming": hny.HAMMING}[mname]
+    x = gen_data(torch, n, dim, "clustered", 42, torch.device("cuda", 0)).cpu().numpy()
+    items = hny.ItemSet.from_f32(metric, x)
+    del x
+    levels = hny.draw_levels(42, M, n)  # what hny_build draws from StdRng::seed_from_u64(42)
+    items.levels = levels
+    bmax = hny.default_batch_max(n)
+    g = hny.build(items, M=M, M0=2 * M, ef_construction=ef, seed=42)
+    ds = orc.Dataset(metric, dim, items.ids, items.codes, items.headers, levels)
+    o = orc.build(ds, M=M, M0=2 * M, ef=ef, order=orc.ORDER_WAVE, threads=os.cpu_count() or 1, batch_frac=1.0,
+                  batch_max=bmax)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added
+    assert g.n_evals_walk == o.n_evals_walk
+    assert g.n_tie_pool_overflow == 0 and len(g.rec_item) == int(levels.astype(np.int64).sum()) + n
+
+
 def test_sharded_deferred_prunes_two_replicas(orc, hny):
     """The multi-GPU apply phase on one GPU: two builders play two ranks.  Each runs the replicated
     part (hny_builder_apply_begin), re-prunes only its half of the overflowing targets
