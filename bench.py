@@ -49,9 +49,9 @@ def parse():
     p.add_argument("--ef", type=int, default=100)
     p.add_argument("--data", default="clustered", choices=["clustered", "overlap", "uniform"])
     p.add_argument("--alt-data", default=None, choices=["overlap", "uniform", "clustered", "none"],
-                   help="second distribution measured in the same run (value_alt / roofline_alt): three more "
-                        "builds; default none")
-    p.add_argument("--alt-steps", type=int, default=2)
+                   help="second distribution measured in the same run (value_alt / roofline_alt / recall_at_10_alt): "
+                        "one warm-up + --alt-steps builds.  Default: overlap for the headline C2 workload, else none")
+    p.add_argument("--alt-steps", type=int, default=1)
     p.add_argument("--cpu-full", action="store_true",
                    help="time the CPU baseline on ALL vectors (about 80-100 s at C2) instead of a bounded sample")
     p.add_argument("--batch-frac", type=float, default=0.0)
@@ -60,7 +60,10 @@ def parse():
     p.add_argument("--ef-search", type=int, default=100)
     p.add_argument("--cpu-sample", type=int, default=0,
                    help="items in the CPU baseline sample; 0 = calibrate for about --cpu-seconds of wall time")
-    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--cpu-seconds", type=float, default=6.0)
+    p.add_argument("--cpu-threads", type=int, default=0,
+                   help="threads of the CPU baseline; 0 = the best of the committed sweep "
+                        "(profiles/r04_cpu_baseline_thread_sweep.json), else what the cgroup's CPU quota grants")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-recall", action="store_true")
     p.add_argument("--seed", type=int, default=42)
@@ -359,6 +362,41 @@ def main():
             r["traffic_stale"] = pj.get("kernel_source_sha1") != sha  # kernels changed since the PMC passes
         return r
 
+    def roofline_issue_of(g, data_kind):
+        """Rows of at most 512 B: the walk is bound by instruction issue, not by bytes.  The record
+        prices it against the issue ports: one vector and one scalar instruction per SIMD every 4 cycles, 1 024
+        SIMDs, 2.4 GHz.  Instructions per evaluation come from the committed rocprofv3 --pmc SQ_* passes of
+        this workload (scripts/r4_sq.sh -> profiles/r04_sq_<workload>.json), the rate from THIS run's k_walk time."""
+        if row_bytes > 512 or g.t_walk_kernels_s <= 0 or world != 1 or a.native:
+            return None
+        if a.batch_frac or a.batch_max or a.x86_order:
+            return None
+        key = f"{a.n}x{a.dim}_{a.metric}_M{a.M}_ef{a.ef}_{data_kind}"
+        import glob
+        names = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_sq_{key}.json")), reverse=True)
+        if not names:
+            return None
+        with open(names[0]) as f:
+            sj = json.load(f)
+        kw_ = sj.get("k_walk")
+        if not kw_ or not kw_.get("evals"):
+            return None
+        import hashlib
+        with open(os.path.join(ROOT, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb") as f:
+            sha = hashlib.sha1(f.read()).hexdigest()
+        v_pe, s_pe = kw_["SQ_INSTS_VALU"] / kw_["evals"], kw_["SQ_INSTS_SALU"] / kw_["evals"]
+        peak = 1024 * 2.4e9 / 4 / 1e9  # G instructions / s per issue port
+        ach_v = v_pe * g.n_evals_walk / g.t_walk_kernels_s / 1e9
+        ach_s = s_pe * g.n_evals_walk / g.t_walk_kernels_s / 1e9
+        return {"bound": "valu-issue", "kernel": "k_walk", "insts_per_eval": round(v_pe, 2),
+                "scalar_insts_per_eval": round(s_pe, 2), "achieved": round(ach_v, 1), "peak": round(peak, 1),
+                "unit": "G vector instructions/s", "frac": round(ach_v / peak, 4),
+                "frac_scalar_port": round(ach_s / peak, 4),
+                "wave_cycles_waiting": round(kw_.get("SQ_WAIT_ANY", 0) / max(1.0, kw_.get("SQ_WAVE_CYCLES_p2", 1.0)), 3),
+                "wave_cycles_issue_stalled": round(kw_.get("SQ_WAIT_INST_ANY", 0) / max(1.0, kw_.get("SQ_WAVE_CYCLES_p2", 1.0)), 3),
+                "source": f"profiles/{os.path.basename(names[0])} (rocprofv3 --pmc SQ_*, scripts/r4_sq.sh)",
+                "stale": sj.get("kernel_source_sha1") != sha}
+
     def pmc_profile(data_kind):
         """the committed PMC summary of this exact workload (newest round first), or (None, None)"""
         if a.batch_frac or a.batch_max or a.x86_order:
@@ -389,6 +427,7 @@ def main():
     builder, driver, graph, dt = timed_builds(items, a.steps, a.warmup)
     value = a.n * a.steps / dt if a.steps else 0.0
     roof = roofline_of(graph, dt, a.steps, a.data)
+    roof_issue = roofline_issue_of(graph, a.data)
     default_c2 = (a.n == 1_000_000 and a.dim == 768 and a.metric == "cosine" and a.M == 16
                   and a.ef == 100 and a.data == "clustered" and not a.batch_frac and not a.batch_max
                   and world == 1 and not a.native and not a.x86_order)
@@ -419,6 +458,8 @@ def main():
         "ranks_seen": (builder._mb.world if a.native else dist.get_world_size() if world > 1 else 1),
         "launcher": launcher,
     }
+    if roof_issue:
+        out["roofline_issue"] = roof_issue
     if a.native:
         out["devices"] = [int(d) for d in builder._mb.opts.devices[:a.gpus]]
     elif world > 1:
@@ -451,8 +492,20 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle = port of the reference algorithm ----
     if rank == 0 and a.gpus == 1 and not a.no_cpu:
         from oracle import orc
-        from tests.conftest import draw_levels
-        cores = os.cpu_count() or 1
+
+        def draw_levels(n_, M_, seed_):  # the levels hny_build itself would draw (rand 0.8.5 StdRng, hnsw.rs:113-119)
+            return H.draw_levels(seed_, M_, n_)
+        # threads: the best of the committed sweep on this kind of box, else what the CPU quota grants
+        # (a GPU box shows 256 logical CPUs and grants 16 CPUs' worth of time)
+        cores = a.cpu_threads or orc.host_threads()
+        sweep_path = os.path.join(ROOT, "profiles", "r04_cpu_baseline_thread_sweep.json")
+        sweep_note = None
+        if not a.cpu_threads and os.path.exists(sweep_path):
+            with open(sweep_path) as f:
+                sw = json.load(f)
+            if sw.get("best_threads") and sw.get("host_threads") == orc.host_threads():
+                cores = int(sw["best_threads"])
+                sweep_note = "profiles/r04_cpu_baseline_thread_sweep.json"
         ns = a.n if a.cpu_full else min(a.cpu_sample, a.n)
         if ns <= 0:  # calibrate on 4000 items, then size the sample for ~cpu_seconds of wall time
             nc = min(4000, a.n)
@@ -471,6 +524,7 @@ def main():
         tc = time.perf_counter() - t1
         out["cpu_baseline"] = {
             "value": round(ns / tc, 1), "unit": "vectors/s", "cores": cores, "kind": "port",
+            "host": {"logical_cpus": os.cpu_count(), "cpu_quota": orc.host_threads(), "threads_chosen_from": sweep_note},
             "size": "port-full" if ns == a.n else "port-sample",
             "sample": (f"all {a.n} vectors" if ns == a.n else
                        f"first {ns} of the {a.n} vectors (a smaller index is cheaper per insert than the "
@@ -501,7 +555,7 @@ def main():
     # ---- a second distribution in the same line: the headline data (well-separated clusters) is the
     # friendly case for the memory system; `overlap` (overlapping clusters on a 32-d manifold) is what
     # embedding collections look like.  value_alt / roofline_alt / recall_at_10_alt, same parameters.
-    alt = a.alt_data or "none"
+    alt = a.alt_data or ("overlap" if default_c2 else "none")
     if a.gpus == 1 and not a.native and alt != "none" and alt != a.data:
         builder.close()
         del x_dev, x, items

@@ -195,6 +195,20 @@ def sqeuclid_emulated(a, b):
     return np.float32(lib().orc_sqeuclid_x86_emulated(a.size, _p(a), _p(b)))
 
 
+def host_threads():
+    """CPU threads this process may actually run at once: os.cpu_count() clipped by the cgroup's CPU quota
+    (a GPU box shows 256 logical CPUs and grants 16 CPUs' worth of time: 256 worker threads then share them)."""
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def level_probas(M):
     out = np.zeros(64, dtype=np.float32)
     n = lib().orc_level_probas(M, _p(out), 64)

@@ -3,6 +3,7 @@
 # two builds of the library (LIBS="path1 path2", default: the in-tree one):
 #   gpurun --timeout 900 -- 'NAME=c5 ARGS="--items 5000000 --dim 1024 --metric hamming --ef 64" LIBS="hannoy_amd/libhannoy_amd_r3.so hannoy_amd/libhannoy_amd.so" bash scripts/r4_sq.sh'
 # -> gpurun_out/r4_sq/<NAME>_summary.txt (per kernel family: counters, per-evaluation instruction counts, issue-roof fractions)
+#    KEY=5000000x1024_hamming_M16_ef64_clustered also writes gpurun_out/r4_sq/r04_sq_<KEY>.json (-> profiles/: bench.py's roofline_issue)
 export TMPDIR=/tmp
 out=gpurun_out/r4_sq
 mkdir -p $out
@@ -25,6 +26,6 @@ for lib in $LIBS; do
     grep -a '"metric"' $d.log | tail -1 > $out/${NAME}_${tag}_p$i.json
     rm -rf $d
   done
-  python3 scripts/r4_sq_summary.py $tag $out/${NAME}_${tag}_p1.csv $out/${NAME}_${tag}_p2.csv $out/${NAME}_${tag}_p1.json | tee -a $out/${NAME}_summary.txt
+  python3 scripts/r4_sq_summary.py $tag $out/${NAME}_${tag}_p1.csv $out/${NAME}_${tag}_p2.csv $out/${NAME}_${tag}_p1.json ${KEY:+$out/r04_sq_${KEY}.json} | tee -a $out/${NAME}_summary.txt
   rm -f $out/${NAME}_${tag}_p1.csv $out/${NAME}_${tag}_p2.csv
 done

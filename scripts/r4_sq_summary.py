@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per kernel family: SQ counters of two rocprofv3 --pmc passes, instructions per walk evaluation, and the
 instruction-issue roof (one VALU and one scalar instruction per SIMD every quad-cycle).
-usage: r4_sq_summary.py TAG pass1.csv pass2.csv bench.json"""
+usage: r4_sq_summary.py TAG pass1.csv pass2.csv bench.json [out.json]
+out.json (-> profiles/r04_sq_<n>x<dim>_<metric>_M<M>_ef<ef>_<data>.json) is what bench.py's `roofline_issue` reads."""
 import collections
 import csv
 import json
@@ -10,6 +11,7 @@ import sys
 FAMS = ("k_walk_heap", "k_walk", "k_prune_n8", "k_apply_n8", "k_prune_wg", "k_apply_wg", "k_apply_append", "k_apply",
         "k_emit", "k_segments")
 tag, p1, p2, bj = sys.argv[1:5]
+out_json = sys.argv[5] if len(sys.argv) > 5 else None
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for path in (p1, p2):
@@ -48,3 +50,20 @@ for fam in FAMS:
                 quads = 1024 * secs[fam] * clk / 4
                 print(f"   issue-port occupancy at {clk / 1e9:.1f} GHz over the kernel's {secs[fam]} s: "
                       f"VALU {valu_q / quads:.3f}  scalar {sca_q / quads:.3f}")
+
+if out_json:
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb") as f:
+        sha = hashlib.sha1(f.read()).hexdigest()
+    res = {"workload": j.get("config", {}).get("workload"), "kernel_source_sha1": sha, "library": tag,
+           "passes": "rocprofv3 --pmc, two passes of 8 SQ counters, one build each (scripts/r4_sq.sh); SQ_ACTIVE_* / "
+                     "SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles summed over waves",
+           "walk_seconds_under_profiler": b["t_walk_kernels_s"]}
+    for fam in FAMS:
+        if fam in agg:
+            res[fam] = dict(agg[fam])
+            if evals.get(fam):
+                res[fam]["evals"] = evals[fam]
+    json.dump(res, open(out_json, "w"), indent=1)
