@@ -262,10 +262,8 @@ struct hny_builder {
   uint32_t bmax = 0;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;          // prune of chunk i overlaps the walk of chunk i+1
   std::vector<hipEvent_t> sync_evs;       // cross-stream dependencies (no timing)
   size_t sync_used = 0;
-  bool overlap = true;
   // schedule state
   size_t pos = 0;
   uint64_t n_done = 0, n_batches = 0;
@@ -300,7 +298,6 @@ struct hny_builder {
   int stage_rows = 0;      // selected rows staged in LDS by the workgroup prune kernels
   u32 cur_n_ops = 0, cur_n_def = 0; // of the batch being applied
   bool apply_open = false;          // between hny_builder_apply_begin and _merge
-  int prune_nw = 4;        // candidates per chunk (= waves per workgroup) of k_prune_wg
   int vis_slots_env = -1;  // HNY_VIS_SLOTS: LDS visited table entries per walk wave, -1 = auto
   bool wave_prune_only = false;
   size_t max_ops = 0, sel_words = 0;
@@ -316,7 +313,6 @@ struct hny_builder {
   uint64_t n_walk_dispatch = 0; // k_walk launches since the last reset
   ~hny_builder() {
     for (auto &e : sync_evs) (void)hipEventDestroy(e);
-    if (stream2) (void)hipStreamDestroy(stream2);
     if (h_l0) (void)hipHostFree(h_l0);
     if (h_up) (void)hipHostFree(h_up);
     if (h_cnt0) (void)hipHostFree(h_cnt0);
@@ -670,7 +666,6 @@ void hny_builder_destroy(hny_builder *b) {
   if (b->stream) {
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
-    if (b->stream2) (void)hipStreamSynchronize(b->stream2);
     (void)hipStreamDestroy(b->stream);
   }
   delete b;
@@ -734,8 +729,6 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     HIP_TRY(hipGetDevice(&b->device));
   }
   HIP_TRY(hipStreamCreate(&b->stream));
-  HIP_TRY(hipStreamCreate(&b->stream2));
-  b->overlap = env_int("HNY_OVERLAP", 0) != 0; // measured slower (prune WGs compete with the walk for LDS/VGPRs)
   hipStream_t st = b->stream;
   double t0 = now_s();
 
@@ -926,11 +919,10 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     b->stage_rows = sl / rpg * rpg;
     // the workgroup prune kernels carry their own wave-order arithmetic: strict mode and very long
     // rows use the single-wave kernels, which all go through dist_rows
-    b->wave_prune_only = env_int("HNY_PRUNE_WAVE", 0) != 0 || b->shape.nch > 8 || o.x86_order;
+    b->wave_prune_only = b->shape.nch > 8 || o.x86_order; // the one-wave prune: strict mode, rows beyond 8 KB
     if (bigcap && b->wave_prune_only)
-      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d needs the workgroup prune kernels (rows <= 8 KB, HNY_PRUNE_WAVE unset)",
+      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d needs the workgroup prune kernels (rows <= 8 KB, wave order)",
                   o.M0, HNY_MAX_CAP);
-    b->prune_nw = env_int("HNY_PRUNE_NW", 4) == 8 ? 8 : 4;
   }
 
   // ---- device memory ----
@@ -1233,7 +1225,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     }
     if (b->wave_prune_only)
       return hnyk_prune(b->g, p, b->shape, (int)std::min<uint32_t>(p.hi - p.lo, b->walk_slots), st);
-    return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, b->prune_nw, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
+    return hnyk_prune_wg(b->g, p, b->shape, b->stage_rows, 4, (int)std::min<uint32_t>(p.hi - p.lo, 2048), st);
   };
   // XCD-tiled work queue of the level-0 walks (WalkArgs.xcd_tile): rows of 1 KB and more, where the walk
   // is HBM-bound and neighbouring queries on one L2 save fabric traffic (C2 walk 0.312 -> 0.289 s, C3
@@ -1278,34 +1270,6 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   };
 
   const uint32_t cnt = hi - lo;
-  if (L == 0 && b->overlap && cnt >= 8192) {
-    // level-0 batch: 4 chunks; walks run back to back on the main stream, the prune of chunk i
-    // runs on stream2 as soon as walk i is done, i.e. under walk i+1 and in walk i's launch tail
-    const uint32_t C = 4, per = (cnt + C - 1) / C;
-    hipEvent_t ev;
-    HIP_TRY(next_sync_event(b, &ev)); // stream2 must not run ahead of the previous apply
-    HIP_TRY(hipEventRecord(ev, b->stream));
-    HIP_TRY(hipStreamWaitEvent(b->stream2, ev, 0));
-    for (uint32_t c = 0; c < C; c++) {
-      const uint32_t clo = lo + c * per, chi = std::min(hi, clo + per);
-      if (clo >= chi) break;
-      WalkArgs w = walk_args(0, clo, chi, queues + c);
-      prof_begin(b, EV_WALK);
-      b->n_walk_dispatch++;
-    HIP_TRY(launch_walk(w, b->stream));
-      prof_end(b);
-      HIP_TRY(next_sync_event(b, &ev));
-      HIP_TRY(hipEventRecord(ev, b->stream));
-      HIP_TRY(hipStreamWaitEvent(b->stream2, ev, 0));
-      prof_begin(b, EV_PRUNE, b->stream2);
-      HIP_TRY(launch_prune(prune_args(0, clo, chi), b->stream2));
-      prof_end(b, b->stream2);
-    }
-    HIP_TRY(next_sync_event(b, &ev));
-    HIP_TRY(hipEventRecord(ev, b->stream2));
-    HIP_TRY(hipStreamWaitEvent(b->stream, ev, 0));
-    return HNY_OK;
-  }
   if (b->locality && b->max_level > L && cnt >= 2048) {
     // batch in LOCALITY ORDER: (1) greedy descent for every member, recording the closest node of
     // the last greedy layers as a coarse-to-fine key; (2) sort the members by that key; (3) the beam
@@ -1396,12 +1360,10 @@ static int apply_front(hny_builder *b, const void *sel_dev, ApplyArgs &a) {
   a.n_deferred = b->d_nseg.p + 1;
   const int grid = (int)std::min<u32>(std::max<u32>(n_ops / 2, 1), 8192);
   prof_begin(b, EV_APPLY);
-  // HNY_APPLY_WAVE=1 (one wave per target, k_apply) keeps one lane per list slot: lists of more than
-  // HNY_MAX_CAP slots always take the append + workgroup path
-  if (a.deferred && (env_int("HNY_APPLY_WAVE", 0) == 0 || std::max(b->g.M0, b->g.M) > (u32)HNY_MAX_CAP))
-    HIP_TRY(hnyk_apply_append(b->g, a, b->stream)); // appends: one thread per target
-  else
-    HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream)); // one wave per target, prunes included
+  if (a.deferred)
+    HIP_TRY(hnyk_apply_append(b->g, a, b->stream)); // appends: one thread per target; overflowing lists deferred
+  else // strict mode / rows beyond 8 KB: one wave per target (one lane per list slot), prunes included
+    HIP_TRY(hnyk_apply(b->g, a, b->shape, grid, b->stream));
   prof_end(b);
   b->cur_n_ops = n_ops;
   return HNY_OK;

@@ -4461,17 +4461,6 @@ struct Hot {
         return hipErrorInvalidValue; // 4 rows x C chunks do not fit the register file: wave prune
       } else {
         size_t lds = wg_prune_lds_bytes((SP == 0 && a.list_global) ? 0u : a.rcap, g.row_stride, SL, nw, wg_capmax(g));
-        if constexpr (SP == 0) {
-          if (nw == 8) {
-            if (lds > 65536) {
-              hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prune_wg<L, C, 8, 0>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-              if (rc != hipSuccess) return rc;
-            }
-            hipLaunchKernelGGL((k_prune_wg<L, C, 8, 0>), dim3(grid), dim3(512), lds, st, g, a, SL);
-            return hipGetLastError();
-          }
-        }
         if (lds > 65536) { // wide lists (M0 up to HNY_BIG_CAP) next to long rows
           hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prune_wg<L, C, 4, SP>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Recall parity of GPU-built vs CPU-built indexes for C4 / C5, with the comparator's OWN spread next to it.
+
+north_star: "Reader recall@10 on the produced index matches CPU-built recall +-0.5 %".  Round 3 compared one GPU
+build with one CPU build made by 256 racing threads (on 16 cores' worth of CPU time) and found the GPU-built index
+0.7 - 2.2 points BETTER on C4 / C5 — while two CPU builds of the same data differed by 1.5 points: the instrument
+was coarser than the band.  This script
+  (1) full size, a distribution where recall means something (--data overlap: overlapping clusters on a 32-d
+      manifold; for Hamming its sign bits — what binary-quantised embeddings look like): GPU build vs CPU build
+      (rayon-like on the box's CPU quota), recall@10 at ef_search 100 ... 1 600, the band at the first ef_search
+      where the CPU-built index reaches 0.9;
+  (2) the comparator's spread on a prefix (--prefix, default 1M): sequential build (1 thread = the reference's
+      deterministic mode), 8 threads x 3 and 32 threads x 3 (the reference's benchmark regime,
+      docs/benchmarks/arroy_hannoy.md:2; thread interleaving differs from run to run), and the GPU build of the
+      same prefix — all searched by the same searcher against exact ground truth.
+
+  gpurun --timeout 1200 -- 'python scripts/r4_recall_parity.py --config C5 [--data overlap] [--skip-full]'
+writes gpurun_out/r04_<config>_recall_parity[_<data>].json (-> profiles/)."""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {"C2": dict(n=1_000_000, dim=768, metric="cosine", M=16, ef=100),
+           "C3": dict(n=1_000_000, dim=768, metric="euclidean", M=32, ef=200),
+           "C4": dict(n=10_000_000, dim=128, metric="cosine", M=16, ef=100),
+           "C5": dict(n=5_000_000, dim=1024, metric="hamming", M=16, ef=64)}
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--config", default="C5", choices=sorted(CONFIGS))
+    p.add_argument("--data", default="overlap")
+    p.add_argument("--items", type=int, default=0)
+    p.add_argument("--prefix", type=int, default=1_000_000)
+    p.add_argument("--queries", type=int, default=1000)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--skip-full", action="store_true")
+    p.add_argument("--skip-spread", action="store_true")
+    p.add_argument("--repeats", type=int, default=3)
+    a = p.parse_args()
+    c = dict(CONFIGS[a.config])
+    if a.items:
+        c["n"] = a.items
+    import torch
+    import bench
+    import hannoy_amd as H
+    from oracle import orc
+    stop, phase = threading.Event(), ["start"]
+
+    def beat():
+        t0 = time.time()
+        while not stop.wait(45):
+            print(f"[r4_recall_parity] {phase[0]} ... {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+    dev = torch.device("cuda", 0)
+    metric = {"cosine": H.COSINE, "euclidean": H.EUCLIDEAN, "hamming": H.HAMMING}[c["metric"]]
+    M, M0, ef = c["M"], 2 * c["M"], c["ef"]
+    threads = orc.host_threads()
+    out_path = os.path.join(ROOT, "gpurun_out", f"r04_{a.config.lower()}_recall_parity" +
+                            ("" if a.data == "overlap" else "_" + a.data) + ".json")
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    out = {"config": a.config, **c, "M0": M0, "data": a.data, "queries": a.queries,
+           "host": {"logical_cpus": os.cpu_count(), "cpu_quota": threads},
+           "levels": "StdRng::seed_from_u64(%d)" % a.seed}
+    efs = [100, 200, 400, 800, 1600]
+
+    def save():
+        json.dump(out, open(out_path, "w"), indent=1)
+
+    phase[0] = "data"
+    x_dev = bench.gen_data(torch, c["n"], c["dim"], a.data, a.seed, dev)
+    q_dev = bench.gen_data(torch, a.queries, c["dim"], a.data, a.seed, dev, queries=True)
+    qc, qh = H.encode_vectors(metric, q_dev.cpu().numpy())
+
+    def recalls(builder, truth, ef_list):
+        r = {}
+        for e in ef_list:
+            ids, _, cnt = builder.search_knn(qc, qh, k=10, ef_search=e)
+            r[str(e)] = round(bench.recall_at_k(ids, cnt, truth), 4)
+        return r
+
+    # ---- (2) the comparator's own spread, on a prefix
+    if not a.skip_spread:
+        npre = min(a.prefix, c["n"])
+        phase[0] = f"prefix of {npre}: ground truth"
+        truth_p = bench.brute_force_topk(torch, c["metric"], x_dev[:npre], q_dev, 10)
+        xp = x_dev[:npre].cpu().numpy()
+        lv = H.draw_levels(a.seed, M, npre)
+        items = H.ItemSet.from_f32(metric, xp, levels=lv)
+        del xp
+        ds = orc.Dataset(metric, c["dim"], items.ids, items.codes, items.headers, lv)
+        sp = {"n": npre, "ef_search": [100, 400], "builds": []}
+        phase[0] = "prefix: GPU build"
+        with H.Builder(items, M=M, M0=M0, ef_construction=ef) as b:
+            b.run()
+            g = b.finish()
+            sp["builds"].append({"who": "gpu (default schedule)", "links": int(len(g.nbrs)),
+                                 "recall_at_10": recalls(b, truth_p, [100, 400])})
+            del g
+        plan = [("cpu sequential (1 thread)", 1, 1)] + [(f"cpu rayon-like {t} threads", t, a.repeats) for t in (8, 32)]
+        for who, t, reps in plan:
+            for r_ in range(reps):
+                phase[0] = f"prefix: {who}, run {r_ + 1}"
+                t0 = time.perf_counter()
+                og = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, threads=t)
+                dt = time.perf_counter() - t0
+                with H.Builder(items, prev=og, load=True, M=M, M0=M0, ef_construction=ef) as b:
+                    rr = recalls(b, truth_p, [100, 400])
+                sp["builds"].append({"who": who, "run": r_ + 1, "seconds": round(dt, 1), "links": int(len(og.nbrs)),
+                                     "recall_at_10": rr})
+                print(json.dumps(sp["builds"][-1]), flush=True)
+                del og
+        for e in ("100", "400"):
+            cpu = [b_["recall_at_10"][e] for b_ in sp["builds"] if b_["who"].startswith("cpu")]
+            gpu = sp["builds"][0]["recall_at_10"][e]
+            sp[f"at_ef_search_{e}"] = {"gpu_built": gpu, "cpu_built_min": min(cpu), "cpu_built_max": max(cpu),
+                                       "cpu_spread": round(max(cpu) - min(cpu), 4),
+                                       "cpu_sequential": sp["builds"][1]["recall_at_10"][e],
+                                       "gpu_minus_cpu_sequential": round(gpu - sp["builds"][1]["recall_at_10"][e], 4),
+                                       "gpu_inside_cpu_range_pm_half_percent":
+                                           bool(min(cpu) - 0.005 <= gpu <= max(cpu) + 0.005)}
+        out["comparator_spread_on_prefix"] = sp
+        save()
+        del items, ds
+
+    # ---- (1) full size
+    if not a.skip_full:
+        phase[0] = "full size: ground truth"
+        truth = bench.brute_force_topk(torch, c["metric"], x_dev, q_dev, 10)
+        x = x_dev.cpu().numpy()
+        del x_dev
+        levels = H.draw_levels(a.seed, M, c["n"])
+        items = H.ItemSet.from_f32(metric, x, levels=levels)
+        del x
+        phase[0] = "full size: GPU build"
+        with H.Builder(items, M=M, M0=M0, ef_construction=ef) as b:
+            b.run()
+            b.finish()
+            b.reset()
+            t0 = time.perf_counter()
+            b.run()
+            gg = b.finish()
+            out["gpu_build_s"] = round(time.perf_counter() - t0, 4)
+            out["gpu_vec_per_s"] = round(c["n"] / out["gpu_build_s"], 1)
+            rg = recalls(b, truth, efs)
+        out["gpu_links"] = int(len(gg.nbrs))
+        del gg
+        save()
+        phase[0] = f"full size: CPU build ({threads} threads)"
+        ds = orc.Dataset(metric, c["dim"], items.ids, items.codes, items.headers, levels)
+        t0 = time.perf_counter()
+        og = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, threads=threads)
+        out["cpu_build_s"] = round(time.perf_counter() - t0, 2)
+        out["cpu_threads"] = threads
+        out["cpu_vec_per_s"] = round(c["n"] / out["cpu_build_s"], 1)
+        out["cpu_links"] = int(len(og.nbrs))
+        phase[0] = "full size: search of the CPU-built graph"
+        with H.Builder(items, prev=og, load=True, M=M, M0=M0, ef_construction=ef) as b:
+            rc = recalls(b, truth, efs)
+        first = next((e for e in efs if rc[str(e)] >= 0.9), None)
+        out["recall_at_10"] = {str(e): {"gpu_built": rg[str(e)], "cpu_built": rc[str(e)],
+                                        "diff": round(rg[str(e)] - rc[str(e)], 4)} for e in efs}
+        out["ef_search_where_cpu_built_reaches_0.9"] = first
+        if first is not None:
+            d = out["recall_at_10"][str(first)]["diff"]
+            out["band_at_that_ef_search"] = {"ef_search": first, "gpu_minus_cpu": d, "within_half_percent": bool(abs(d) <= 0.005)}
+        out["within_half_percent_everywhere"] = all(abs(v["diff"]) <= 0.005 for v in out["recall_at_10"].values())
+        save()
+    stop.set()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

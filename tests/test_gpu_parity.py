@@ -423,18 +423,6 @@ def test_visited_log_overflow_fallback(orc, hny, monkeypatch):
     assert g.n_evals_walk / n > 1024  # the log (1024 entries) must have overflowed
 
 
-def test_wave_prune_variant_matches(orc, hny, monkeypatch):
-    """HNY_PRUNE_WAVE=1 (single-wave prune without LDS staging) builds the same graph."""
-    monkeypatch.setenv("HNY_PRUNE_WAVE", "1")
-    rng = np.random.default_rng(4)
-    n, dim = 3000, 64
-    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
-    ds, items = _mk(orc, hny, 0, vecs, draw_levels(n, 8, seed=4))
-    o = orc.build(ds, M=8, M0=16, ef=64, order=orc.ORDER_WAVE, batch_frac=0.25, batch_max=256)
-    g = hny.build(items, M=8, M0=16, ef_construction=64, batch_frac=0.25, batch_max=256)
-    _same_graph(g, o)
-
-
 def test_full_size_c2_properties(orc, hny):
     """BASELINE config C2 at full size (1M x 768 cosine, M=16, efC=100) through size-independent
     properties: the build is deterministic (two builds, identical records), every record is valid
@@ -859,15 +847,12 @@ def test_lds_visited_table_and_spill_equal_oracle(orc, hny, slots, monkeypatch):
             assert np.array_equal(got_[1][r, :c].view(np.uint32), want[1][r, :c].view(np.uint32))
 
 
-@pytest.mark.parametrize("env", [{"HNY_OVERLAP": "1"}, {"HNY_PRUNE_NW": "8"}, {"HNY_NO_LOCALITY": "1"},
-                                 {"HNY_STAGE_BYTES": "0"}, {"HNY_STAGE_BYTES": "8192", "HNY_PRUNE_NW": "8"},
-                                 {"HNY_NO_RB": "1"}, {"HNY_NO_FAST": "1"},
-                                 {"HNY_NO_FAST": "1", "HNY_PRUNE_NW": "8"}])  # 8-wave chunks exist in the general kernels only
+@pytest.mark.parametrize("env", [{"HNY_NO_LOCALITY": "1"}, {"HNY_STAGE_BYTES": "0"}, {"HNY_STAGE_BYTES": "8192"},
+                                 {"HNY_NO_RB": "1"}, {"HNY_NO_FAST": "1"}])
 def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
-    """Every measured-and-rejected variant that is still selectable by environment (DESIGN.md "what
-    did not pay") must build the oracle's graph too: overlapped chunked prune, 8-wave prune chunks,
-    no locality order, no / small LDS stage; and the LDS beam (HNY_NO_RB) / the general kernels
-    (HNY_NO_FAST) where the register beam / the specialised kernels are the default (256-d rows)."""
+    """Every switch that is still selectable by environment must build the oracle's graph too: no locality
+    order, no / small LDS stage; the LDS beam (HNY_NO_RB) / the general kernels (HNY_NO_FAST) where the
+    register beam / the specialised kernels are the default (256-d rows)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(5)
@@ -877,6 +862,29 @@ def test_tuning_knobs_do_not_change_the_graph(orc, hny, env, monkeypatch):
     o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=4096)
     g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=4096)
     _same_graph(g, o)
+
+
+@pytest.mark.parametrize("buckets", ["0", "64", "192", None])
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef", [(3, 9000, 1024, 16, 32, 64), (0, 9000, 128, 16, 32, 100),
+                                                  (1, 6000, 100, 8, 16, 48), (4, 5000, 2048, 12, 24, 40),
+                                                  (3, 7000, 200, 16, 64, 100)])
+def test_short_row_visited_bucket_table_equals_oracle(orc, hny, monkeypatch, buckets, metric, n, dim, M, M0, ef):
+    """walk_layer_short's visited set (rows <= 512 B): buckets of four 16-bit remainders in LDS, the HBM bitset
+    behind them for ids whose bucket is full.  Without the table (0), with one that overflows all the time
+    (64 buckets = 256 ids for walks that mark ~1 000), a small one, and the default: the oracle's graph and
+    evaluation counts every time — 8-, 16- and 32-lane row shapes, partial last units (100-d), full lists
+    (M0 = 64), ties and duplicate vectors (Hamming), entry points from a layer above."""
+    if buckets is not None:
+        monkeypatch.setenv("HNY_VIS_BUCKETS", buckets)
+    rng = np.random.default_rng(11 * n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    if metric >= 3:
+        vecs[rng.integers(0, n, n // 20)] = vecs[rng.integers(0, n, n // 20)]
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, M, seed=n + 1))
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, batch_frac=1.0, batch_max=2048)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=1.0, batch_max=2048)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
 @pytest.mark.parametrize("metric", range(7))
