@@ -372,7 +372,7 @@ static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
 // the walk's occupancy: 8 KB of LDS per wave at 5 waves per SIMD (binary codes), 10 KB at 4 (f32) — and only
 // while a remainder fits 16 bits (2^k / buckets < 65 535, n < 2^28).  HNY_VIS_BUCKETS overrides (0 = bitset only).
 static void vis_buckets_for(const hny_builder *b, WalkArgs &w) {
-  w.vis_buckets = w.vis_magic = w.vis_smask = 0;
+  w.vis_buckets = w.vis_magic = w.vis_shift = w.vis_smask = 0;
   if ((size_t)b->g.n16 * 16 > 512 || w.vis_slots || w.res_global || w.rcap > 128 || w.eps_cap > 64) return;
   const size_t fixed = hnyk_walk_lds_bytes(w.rcap, w.eps_cap);
   const size_t budget = (b->shape.nch == 1 && b->o.metric >= HNY_HAMMING) ? 8192 : 10240;
@@ -384,7 +384,10 @@ static void vis_buckets_for(const hny_builder *b, WalkArgs &w) {
   while (k < 28 && (1ull << k) < (uint64_t)std::max<uint32_t>(b->g.n, 2)) k++;
   if ((1ull << k) < (uint64_t)b->g.n || ((1ull << k) - 1) / (uint64_t)nb + 1 >= 65535) return;
   w.vis_buckets = (u32)nb;
-  w.vis_magic = (u32)((1ull << 40) / (uint64_t)nb + 1);
+  uint32_t lg = 0;
+  while ((2u << lg) <= (uint32_t)nb) lg++;
+  w.vis_shift = 31 + lg;
+  w.vis_magic = (u32)((1ull << w.vis_shift) / (uint64_t)nb + 1);
   w.vis_smask = (u32)((1ull << k) - 1);
 }
 static void prof_begin(hny_builder *b, int kind, hipStream_t st = nullptr) {

@@ -133,8 +133,9 @@ struct WalkArgs {
   u32 pool_flag;     // reader mode: a query whose tie pool overflowed reports cand_n = 0xFFFFFFFE (the host
                      // repeats it on the heap-queue searcher) instead of counting an error
   // short-row build walks (walk_layer_short): LDS visited table of vis_buckets x 4 x 16-bit remainders, 0 = none
-  // (VisB in hny_kernels.hip); vis_magic = floor(2^40 / vis_buckets) + 1, vis_smask = 2^k - 1 >= n - 1
-  u32 vis_buckets, vis_magic, vis_smask;
+  // (VisB in hny_kernels.hip); vis_magic = floor(2^vis_shift / vis_buckets) + 1 with vis_shift = 31 + floor(log2 buckets)
+  // (the magic then fits 32 bits and x div buckets == (x * magic) >> vis_shift for x < 2^30); vis_smask = 2^k - 1 >= n - 1
+  u32 vis_buckets, vis_magic, vis_shift, vis_smask;
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,

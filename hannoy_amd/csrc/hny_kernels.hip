@@ -1387,7 +1387,8 @@ __device__ __forceinline__ void walk_one_layer(const GraphDev &g, const float4 (
 struct VisB {
   u64 *tb;    // LDS: nb buckets x 4 x u16; null = bitset only
   u32 nb;     // buckets
-  u32 magic;  // floor(2^40 / nb) + 1: sid div nb == (sid * magic) >> 40 for sid < 2^28
+  u32 magic;  // floor(2^shift / nb) + 1, shift = 31 + floor(log2 nb): sid div nb == (sid * magic) >> shift for sid < 2^30
+  u32 shift;
   u32 smask;  // 2^k - 1
 };
 #define HNY_VISB_MUL 0x9E3779B1u
@@ -1406,7 +1407,7 @@ __device__ __forceinline__ bool visb_insert(const VisB &v, Visited &vis, u32 id,
   bool isnew = false, over = valid;
   if (v.tb) { // wave-uniform
     const u32 sid = (id * HNY_VISB_MUL) & v.smask;
-    const u32 q = (u32)(((u64)sid * (u64)v.magic) >> 40);
+    const u32 q = (u32)(((u64)sid * (u64)v.magic) >> v.shift);
     const u32 bk = sid - q * v.nb;
     const u32 r = q + 1u, r2 = r | (r << 16); // the remainder (+ 1) in both halves of a word
     uint2 cur = reinterpret_cast<const uint2 *>(v.tb)[bk]; // (lanes without an id read some bucket too: no exec juggling)
@@ -1809,12 +1810,14 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   vb.tb = nullptr;
   vb.nb = 0;
   vb.magic = 0;
+  vb.shift = 0;
   vb.smask = 0;
   if constexpr (SHORT && !RM) {
     if (a.vis_buckets) { // (behind eps; NO_TAB kernels have no other table there)
       vb.tb = reinterpret_cast<u64 *>(eps + 64);
       vb.nb = a.vis_buckets;
       vb.magic = a.vis_magic;
+      vb.shift = a.vis_shift;
       vb.smask = a.vis_smask;
       visb_clear(vb);
     }
