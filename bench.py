@@ -47,7 +47,7 @@ def parse():
     p.add_argument("--M", type=int, default=16)
     p.add_argument("--M0", type=int, default=0)
     p.add_argument("--ef", type=int, default=100)
-    p.add_argument("--data", default="clustered", choices=["clustered", "overlap", "uniform"])
+    p.add_argument("--data", default="clustered", choices=["clustered", "overlap", "manifold", "uniform"])
     p.add_argument("--alt-data", default=None, choices=["overlap", "uniform", "clustered", "none"],
                    help="second distribution measured in the same run (value_alt / roofline_alt / recall_at_10_alt): "
                         "one warm-up + --alt-steps builds.  Default: overlap for the headline C2 workload, else none")
@@ -146,10 +146,13 @@ def gen_data(torch, n, dim, kind, seed, device, queries=False):
     gn = g2 if queries else g  # the structure (centres, basis) always comes from `g`
     if kind == "uniform":  # reference-style U(-1,1) (src/tests/mod.rs:133-136)
         return torch.rand((n, dim), generator=gn, device=device, dtype=torch.float32) * 2 - 1
-    if kind == "overlap":
+    if kind in ("overlap", "manifold"):
         # embedding-like: 1 024 OVERLAPPING clusters on a 32-d manifold embedded in `dim` dimensions
         # (latent centres N(0, 1), points centre + 0.5 N(0, 1): the spread inside a cluster is half the
         # spread of the centres, so neighbourhoods cross cluster borders) + 0.05 isotropic noise
+        # ("manifold": 0.01 — at 5M / 10M points the manifold is populated so densely that 0.05 of isotropic
+        # noise per component, not the manifold, decides who the ten nearest neighbours are)
+        iso = 0.05 if kind == "overlap" else 0.01
         k = min(32, dim)
         centres = torch.randn((1024, k), generator=g, device=device, dtype=torch.float32)
         basis = torch.linalg.qr(torch.randn((dim, k), generator=g, device=device, dtype=torch.float32))[0].T
@@ -158,7 +161,7 @@ def gen_data(torch, n, dim, kind, seed, device, queries=False):
         for lo in range(0, n, 1 << 18):  # in slices: bounded temporaries
             hi = min(n, lo + (1 << 18))
             z = centres[which[lo:hi]] + 0.5 * torch.randn((hi - lo, k), generator=gn, device=device)
-            out[lo:hi] = z @ basis + 0.05 * torch.randn((hi - lo, dim), generator=gn, device=device)
+            out[lo:hi] = z @ basis + iso * torch.randn((hi - lo, dim), generator=gn, device=device)
         return out
     # 1024-centre Gaussian mixture, centres U(-1,1), sigma 0.15: well separated
     centres = torch.rand((1024, dim), generator=g, device=device, dtype=torch.float32) * 2 - 1

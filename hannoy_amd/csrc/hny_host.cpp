@@ -2039,6 +2039,7 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
     w.eps_cap = eps_cap_of(b);
     w.queue = queues;
     w.cancel = sc.d;
+    vis_buckets_for(b, w);
     w.pool_flag = env_int("HNY_NO_POOL_RETRY", 0) == 0 ? 1u : 0u;
     w.force_pool = (u32)std::max(0, env_int("HNY_POOL_FORCE_RETRY", 0)); // tests: every k-th query takes the retry path
     if (sc.d) HIP_TRY(hnyk_fill_u32(dcn.p, 0xFFFFFFFFu, cnt, b->stream)); // = never finished

@@ -1390,13 +1390,37 @@ struct VisB {
   u32 magic;  // floor(2^shift / nb) + 1, shift = 31 + floor(log2 nb): sid div nb == (sid * magic) >> shift for sid < 2^30
   u32 shift;
   u32 smask;  // 2^k - 1
+  int off;    // the table was flushed into the bitset (Reader's exhaustive fallback): the bitset alone answers
 };
 #define HNY_VISB_MUL 0x9E3779B1u
+#define HNY_VISB_INV 0x0E8B2F51u // HNY_VISB_MUL * HNY_VISB_INV == 1 mod 2^32 (hence mod every 2^k)
 
-__device__ __forceinline__ void visb_clear(const VisB &v) {
+__device__ __forceinline__ void visb_clear(VisB &v) {
   if (!v.tb) return;
   float4 *t4 = reinterpret_cast<float4 *>(v.tb);
   for (u32 i = HNY_LANE; i < v.nb / 2u; i += 64) t4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  v.off = 0;
+  WSYNC();
+}
+
+// copy the table into the bitset so that the bitset alone answers "visited?" (the Reader's exhaustive fallback
+// scans it word by word, reader.rs:771-795); later ids go to the bitset.  bucket and remainder give the id back.
+__device__ __forceinline__ void visb_flush(VisB &v, Visited &vis) {
+  if (!v.tb || v.off) return;
+  for (u32 b = HNY_LANE; b < v.nb; b += 64) {
+    const u64 cur = v.tb[b];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u32 r = (u32)(cur >> (16 * j)) & 0xFFFFu;
+      if (r) {
+        const u32 id = (((r - 1u) * v.nb + b) * HNY_VISB_INV) & v.smask;
+        atomicOr(&vis.bits[id >> 5], 1u << (id & 31));
+      }
+    }
+  }
+  vis.log_over = 1; // not logged: clear the whole bitset afterwards
+  v.off = 1;
+  __threadfence_block();
   WSYNC();
 }
 
@@ -1405,7 +1429,7 @@ __device__ __forceinline__ void visb_clear(const VisB &v) {
 __device__ __forceinline__ bool visb_insert(const VisB &v, Visited &vis, u32 id, bool valid) {
   const u64 lt = (1ull << HNY_LANE) - 1ull;
   bool isnew = false, over = valid;
-  if (v.tb) { // wave-uniform
+  if (v.tb && !v.off) { // wave-uniform
     const u32 sid = (id * HNY_VISB_MUL) & v.smask;
     const u32 q = (u32)(((u64)sid * (u64)v.magic) >> v.shift);
     const u32 bk = sid - q * v.nb;
@@ -1730,14 +1754,14 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
 #define HNY_WALK_WPE 4
 #endif
 // binary codes of at most 1 KB (NCH == 1; no LDS visited table there, so LDS allows it): the
-// specialised kernels fit ~96 VGPRs and run 5 waves per SIMD (Hamming 1024-bit: walk 0.344 ->
-// 0.310 s; 6 would spill).  The f32 kernels of that row size spill 22 VGPRs at 96 and gain nothing
+// specialised BUILD kernels fit ~96 VGPRs and run 5 waves per SIMD (Hamming 1024-bit: walk 0.344 ->
+// 0.310 s; 6 would spill; the Reader's variant carries the exhaustive fallback and spills at 96: 4 waves).  The f32 kernels of that row size spill 22 VGPRs at 96 and gain nothing
 // from the fifth wave; the general kernels already spill at 4.
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 5
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, int RC = 0>
-__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
   constexpr bool RB = RC != 0;
   constexpr int RCN = RC ? RC : 1;
   static_assert(!(RB && (BIG_EPS || SP == 0)), "register beam: specialised kernels only");
@@ -1812,7 +1836,8 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
   vb.magic = 0;
   vb.shift = 0;
   vb.smask = 0;
-  if constexpr (SHORT && !RM) {
+  vb.off = 0;
+  if constexpr (SHORT) {
     if (a.vis_buckets) { // (behind eps; NO_TAB kernels have no other table there)
       vb.tb = reinterpret_cast<u64 *>(eps + 64);
       vb.nb = a.vis_buckets;
@@ -1969,6 +1994,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 ? HNY_WALK_WPE_SMALL : HNY
       const u32 nwords = (g.n + 31) >> 5;
       u32 pos = 0;
       visited_flush(vis);
+      visb_flush(vb, vis);
       while (pos < g.n) {
         const u32 wbase = pos >> 5;
         const u32 widx = wbase + (u32)ln;

@@ -53,7 +53,7 @@ struct Rccl {
   void *handle = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclCommAbort) CommAbort = nullptr; // optional
+  decltype(&ncclCommAbort) CommAbort = nullptr; // required: the only way out of a collective a failed peer never joins
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -76,7 +76,7 @@ int load_rccl() {
   r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
   r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-  if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+  if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString || !r.CommAbort)
     return failf(HNY_ERR_NO_DEVICE, "multi-GPU build: librccl lacks an expected symbol");
   g_rccl = r;
   return HNY_OK;

@@ -68,3 +68,33 @@ def test_a_failing_rank_fails_the_run():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], capture_output=True, text=True, env=_clean_env(),
                        timeout=300)
     assert r.returncode != 0 and "exited with code" in r.stderr and not r.stdout.strip()
+
+
+# ---- the same launch modes with real builds, on the one GPU of the test box (ranks share it) ----
+import pytest  # noqa: E402
+
+SMALL = ["--items", "30000", "--dim", "64", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-recall", "--queries", "0"]
+
+
+@pytest.mark.gpu
+def test_gpus_2_native_builds_on_two_replicas_through_the_copy_shim():
+    """`bench.py --gpus 2 --native`: the resident multi-builder behind the C ABI (hny_multi.cpp) with two replicas on
+    GPU 0, the all-gathers replaced by the copy shim, every replica's export compared inside the library"""
+    env = dict(_clean_env(), HNY_MGPU_SHIM="1", HNY_MGPU_VERIFY="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--native"] + SMALL, capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["launcher"] == "native" and j["replicas_identical"] is True
+    assert j["n_collectives"] > 0 and j["value"] > 0
+
+
+@pytest.mark.gpu
+def test_gpus_2_self_launched_ranks_build_over_gloo_on_one_gpu():
+    """`bench.py --gpus 2 --backend gloo`: two self-launched processes (the torchrun harness, multigpu.py), exchange
+    staged through the host; rank 0 compares the replicas' checksums"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo"] + SMALL, capture_output=True,
+                       text=True, env=_clean_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["ranks_seen"] == 2 and j["launcher"] == "self" and j["replicas_identical"] is True and j["n_collectives"] > 0
