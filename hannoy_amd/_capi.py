@@ -618,6 +618,7 @@ class MultiBuilder:
         self.items = items
         self.opts = make_opts(items.metric, items.dim, n_gpus=n_gpus, devices=devices, **kw)
         self._h = C.c_void_p()
+        self._replicas = []
         it = items.struct()
         _check(load_library().hny_multi_builder_create(C.byref(self.opts), C.byref(it), C.byref(self._h)))
 
@@ -645,10 +646,15 @@ class MultiBuilder:
         b = Builder.__new__(Builder)
         b.items, b.opts, b.incremental = self.items, self.opts, False
         b._h, b._borrowed = C.c_void_p(h), True
+        b._mb = self  # the borrowed handle lives exactly as long as this multi-builder: keep it alive ...
+        self._replicas.append(b)
         return b
 
     def close(self):
         if self._h:
+            for b in self._replicas:  # ... and make a replica handle unusable once it is gone
+                b._h = C.c_void_p()
+            self._replicas = []
             load_library().hny_multi_builder_destroy(self._h)
             self._h = C.c_void_p()
 
