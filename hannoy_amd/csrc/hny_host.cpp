@@ -369,13 +369,15 @@ static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
   return (uint32_t)((10240 - fixed) / 4 / 64 * 64);
 }
 // Short rows (<= 512 B, walk_layer_short): the LDS visited table of 16-bit remainders.  As many buckets as keep
-// the walk's occupancy: 8 KB of LDS per wave at 5 waves per SIMD (binary codes), 10 KB at 4 (f32) — and only
-// while a remainder fits 16 bits (2^k / buckets < 65 535, n < 2^28).  HNY_VIS_BUCKETS overrides (0 = bitset only).
+// the walk's occupancy: 10 KB of LDS per wave at 4 waves per SIMD (f32: 896 buckets; 640: +2 %, 1 024: +5 % walk
+// time at 4M x 128), 7 KB at 5 (binary codes: 512 buckets; 640 and 768 were 3 % / 1.5 % slower at C5, 4 096 waves
+// instead of 5 120 9 %) — and only while a remainder fits 16 bits (2^k / buckets < 65 535, n < 2^28).
+// HNY_VIS_BUCKETS overrides (0 = bitset only).
 static void vis_buckets_for(const hny_builder *b, WalkArgs &w) {
   w.vis_buckets = w.vis_magic = w.vis_shift = w.vis_smask = 0;
   if ((size_t)b->g.n16 * 16 > 512 || w.vis_slots || w.res_global || w.rcap > 128 || w.eps_cap > 64) return;
   const size_t fixed = hnyk_walk_lds_bytes(w.rcap, w.eps_cap);
-  const size_t budget = (b->shape.nch == 1 && b->o.metric >= HNY_HAMMING) ? 8192 : 10240;
+  const size_t budget = (b->shape.nch == 1 && b->o.metric >= HNY_HAMMING) ? 7168 : 10240;
   int nb = fixed + 1024 <= budget ? (int)((budget - fixed) / 8 / 64 * 64) : 0;
   const char *e = getenv("HNY_VIS_BUCKETS");
   if (e && *e) nb = std::max(0, std::min(4096, atoi(e) / 2 * 2));
