@@ -10,7 +10,7 @@ out=gpurun_out/r3_pmc
 mkdir -p $out
 NAME=${NAME:-c2}
 ARGS=${ARGS:-""}
-COMMON="--no-cpu --no-recall --queries 0 --steps 1"
+COMMON="--no-cpu --no-recall --queries 0 --steps 1 --alt-data none"
 rm -rf $out/${NAME}_s $out/${NAME}_f $out/${NAME}_w
 if [ -z "$SKIP_STATS" ]; then
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${NAME}_s -- python3 bench.py $COMMON --warmup 1 $ARGS > $out/${NAME}_s.log 2>&1

@@ -3,7 +3,7 @@
 #   python -m hannoy_amd.buildlib --out hannoy_amd/libhannoy_amd_ph.so   (with HNY_CFLAGS=-DHNY_PHASE_CLOCKS)
 #   gpurun -- 'LIB=hannoy_amd/libhannoy_amd_ph.so CFGS="c5 c4s" bash scripts/r4_phase_clocks.sh'
 mkdir -p gpurun_out/r4_ph
-A="--no-cpu --no-recall --queries 0 --steps 1 --warmup 0"
+A="--no-cpu --no-recall --queries 0 --alt-data none --steps 1 --warmup 0"
 export HNY_LIB=$PWD/${LIB:-hannoy_amd/libhannoy_amd_ph.so}
 for name in ${CFGS:-c5}; do
   case $name in

@@ -21,7 +21,7 @@ for lib in $LIBS; do
     i=$((i+1))
     d=$out/${NAME}_${tag}_p$i
     rm -rf $d
-    timeout -k 10 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -- python3 bench.py --no-cpu --no-recall --queries 0 --steps 1 --warmup 0 $ARGS > $d.log 2>&1 || { echo "pass $i of $tag failed"; tail -5 $d.log; exit 1; }
+    timeout -k 10 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -- python3 bench.py --no-cpu --no-recall --queries 0 --steps 1 --warmup 0 --alt-data none $ARGS > $d.log 2>&1 || { echo "pass $i of $tag failed"; tail -5 $d.log; exit 1; }
     cp $(find $d -name "*counter_collection.csv") $out/${NAME}_${tag}_p$i.csv
     grep -a '"metric"' $d.log | tail -1 > $out/${NAME}_${tag}_p$i.json
     rm -rf $d

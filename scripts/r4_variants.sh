@@ -3,7 +3,7 @@
 #   VARIANTS='base||;tab2048|HNY_SHORT_TAB=2048 HNY_WALK_SLOTS=3584|hannoy_amd/libhannoy_amd_tab.so' CFGS="c5 c4s" bash scripts/r4_variants.sh
 # each variant: name|environment assignments|library (empty = the in-tree build)
 mkdir -p gpurun_out/r4_var
-A="--no-cpu --no-recall --queries 0 --steps ${STEPS:-2} --warmup 1"
+A="--no-cpu --no-recall --queries 0 --alt-data none --steps ${STEPS:-2} --warmup 1"
 CFGS=${CFGS:-"c5"}
 ROUNDS=${ROUNDS:-2}
 IFS=';' read -ra VARS <<< "$VARIANTS"
