@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--ef-search", type=int, default=100)
     p.add_argument("--cpu-sample", type=int, default=0,
                    help="items in the CPU baseline sample; 0 = calibrate for about --cpu-seconds of wall time")
-    p.add_argument("--cpu-seconds", type=float, default=6.0)
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--cpu-threads", type=int, default=0,
                    help="threads of the CPU baseline; 0 = the best of the committed sweep "
                         "(profiles/r04_cpu_baseline_thread_sweep.json), else what the cgroup's CPU quota grants")
@@ -518,7 +518,7 @@ def main():
             orc.build(dsc, M=a.M, M0=M0, ef=a.ef, order=orc.ORDER_X86, threads=cores)
             rate = nc / max(time.perf_counter() - t1, 1e-3)
             # the per-insert cost grows with the index: assume half the calibrated rate
-            ns = int(min(a.n, max(10000, min(200000, 0.5 * rate * a.cpu_seconds))))
+            ns = int(min(a.n, max(10000, 0.5 * rate * a.cpu_seconds)))
         lv = draw_levels(ns, a.M, a.seed)
         ds = orc.Dataset(metric, a.dim, np.arange(ns, dtype=np.uint32), items.codes[:ns],
                          items.headers[:ns], lv)
@@ -534,15 +534,20 @@ def main():
                        f"full one, so this flatters the CPU; --cpu-full times all of them)") +
                       f", same params, vectors in RAM, {cores} threads (rayon-like), AVX2+FMA kernels",
             "seconds": round(tc, 2)}
-        full = os.path.join(ROOT, "profiles", "r03_c2_full_scale_recall_parity.json")
-        if default_c2 and ns != a.n and os.path.exists(full):  # one-off measurement of the same baseline at full size
-            with open(full) as f:
+        # the committed full-size comparison of this workload, if there is one (scripts/r4_recall_parity.py: GPU-built vs
+        # CPU-built index at the BASELINE size, same levels, same searcher, exact ground truth)
+        short = cfg_name.split(" ")[0].lower()
+        fp = os.path.join(ROOT, "profiles", f"r04_{short}_recall_parity" + ("" if a.data == "overlap" else "_" + a.data) + ".json")
+        if short in ("c2", "c3", "c4", "c5") and os.path.exists(fp) and not (a.batch_frac or a.batch_max or a.x86_order):
+            with open(fp) as f:
                 fj = json.load(f)
-            out["cpu_baseline"]["full_size_run"] = {
-                "vectors_per_s": fj["cpu_vec_per_s"], "seconds": fj["cpu_build_s"], "cores": fj["cores"],
-                "recall_at_10_cpu_built": fj["recall_at_10"]["100"]["cpu_built"],
-                "recall_at_10_gpu_built": fj["recall_at_10"]["100"]["gpu_built"],
-                "source": "profiles/r03_c2_full_scale_recall_parity.json (scripts/recall_parity_full.py --config C2)"}
+            if fj.get("n") == a.n and "recall_at_10" in fj:
+                out["cpu_baseline"]["full_size_run"] = {
+                    "vectors_per_s": fj["cpu_vec_per_s"], "seconds": fj["cpu_build_s"], "cores": fj.get("cpu_threads"),
+                    "recall_at_10_cpu_built": fj["recall_at_10"]["100"]["cpu_built"],
+                    "recall_at_10_gpu_built": fj["recall_at_10"]["100"]["gpu_built"],
+                    "recall_at_10_by_ef_search": fj["recall_at_10"],
+                    "source": f"profiles/{os.path.basename(fp)} (scripts/r4_recall_parity.py --config {short.upper()} --data {a.data})"}
         # recall parity on the sample: CPU-built vs GPU-built graph, both searched by the oracle
         if not a.no_recall and a.queries:
             sub = H.ItemSet(metric, a.dim, ds.ids, ds.codes, ds.headers, lv)
