@@ -45,7 +45,7 @@ def main():
     which = sys.argv[1:] or ["C2", "C3", "C5"]
     heartbeat()
     dev = torch.device("cuda", 0)
-    cores = os.cpu_count() or 1
+    cores = orc.host_threads()  # what the cgroup grants (16 on the GPU box), not the 256 logical CPUs it shows
     # On the GPU box only gpurun_out/ travels back, and it starts empty there: a run of SOME configs starts from
     # the committed file (profiles/ travels with the snapshot) and adds to it, so copying the result back to
     # profiles/ never drops the entries of an earlier call (round 3 lost three of four that way).

@@ -593,7 +593,7 @@ def test_mid_size_build_equals_oracle(orc, hny, cfg):
     bmax = hny.default_batch_max(n)
     g = hny.build(items, M=M, M0=2 * M, ef_construction=ef, seed=42)
     ds = orc.Dataset(metric, dim, items.ids, items.codes, items.headers, levels)
-    o = orc.build(ds, M=M, M0=2 * M, ef=ef, order=orc.ORDER_WAVE, threads=os.cpu_count() or 1, batch_frac=1.0,
+    o = orc.build(ds, M=M, M0=2 * M, ef=ef, order=orc.ORDER_WAVE, threads=orc.host_threads(), batch_frac=1.0,
                   batch_max=bmax)
     _same_graph(g, o)
     assert g.n_links_added == o.n_links_added
