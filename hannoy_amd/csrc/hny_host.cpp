@@ -357,12 +357,9 @@ static uint32_t res_capacity(uint32_t ef, uint32_t n_eps, uint64_t n_slots, uint
 static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
   // measured: +5 % on 3 KB rows (C2/C3), -3 % on 512-B rows (the table clear per greedy layer and
   // the longer probes outweigh the saved L2 atomics when a row costs little; round 2, 5M x 1024 bits:
-  // 0.73-0.91 s against 0.66 s): rows > 1 KB only — the specialised short-row kernels are compiled
-  // without the table
-  if ((size_t)b->g.n16 * 16 <= 1024) { // experiment (needs a library built with -DHNY_SHORT_TAB)
-    const char *e = getenv("HNY_SHORT_TAB");
-    return e && *e ? (uint32_t)std::max(0, atoi(e)) : 0u;
-  }
+  // 0.73-0.91 s against 0.66 s; round 4, same table in walk_layer_short: 0.58-0.72 s against 0.59 s): rows > 1 KB
+  // only — rows <= 512 B have their own table of 16-bit remainders (vis_buckets_for)
+  if ((size_t)b->g.n16 * 16 <= 1024) return 0;
   if (b->vis_slots_env >= 0) return (uint32_t)std::min(8192, b->vis_slots_env);
   const size_t fixed = hnyk_walk_lds_bytes(rcap, eps_cap_of(b));
   if (fixed + 512 * 4 > 10240) return 512;

@@ -1822,11 +1822,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM ? HNY_WALK_WPE_SMAL
   // 0.69-0.75, C4-like 0.88 against 0.88: no gain, DESIGN.md §5 "Short rows")
   // rows <= 1 KB never get an LDS table (the host passes vis_slots = 0 for them): say so at compile
   // time in the specialised kernels, so that the table's code and its six wave-uniform fields go
-#ifdef HNY_SHORT_TAB // experiment: the LDS visited table for short rows too (the host passes vis_slots)
-  constexpr bool NO_TAB = false;
-#else
   constexpr bool NO_TAB = SP != 0 && NCH == 1;
-#endif
   visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
                a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u),
                NO_TAB ? 0u : a.vis_slots);
@@ -3441,16 +3437,29 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, const u64 *list,
       if (g.norms) nxt_n = g.norms[nx];
     }
     // (2) against S as it stands
+    // two selected rows per step: `exists i in S` does not care about the order, and the two dependent chains
+    // of a step (LDS read -> fma chain -> 8-lane butterfly -> finaliser -> compare) then overlap inside the wave —
+    // this loop is bound by their latency, not by issue (k_prune_n8: vector port 0.32 busy)
     bool viol = false;
-    for (int j = 0; j < s_len; j++) {
+    for (int j = 0; j < s_len; j += 2) {
       const u64 open = ballot(have && !viol);
       if (!open) break;
-      float4 r[NQ];
-      if (j < SL) load8_lds(stage + (size_t)j * g.row_stride, r);
-      else load8(g.rows + (size_t)s_ids[j] * g.row_stride, r); // beyond the stage (rare): from L2
-      const float d = dist8<LPRO>(g, c, r, cn, s_norm[j]);
-      viol = viol || fbits(d * g.alpha) < cdb; // hnsw.rs:585
-      evals += (u64)(__popcll(open) >> 3);
+      const bool two = j + 1 < s_len; // wave-uniform
+      float4 r0[NQ], r1[NQ];
+      if (j < SL) load8_lds(stage + (size_t)j * g.row_stride, r0);
+      else load8(g.rows + (size_t)s_ids[j] * g.row_stride, r0); // beyond the stage (rare): from L2
+      if (two) {
+        if (j + 1 < SL) load8_lds(stage + (size_t)(j + 1) * g.row_stride, r1);
+        else load8(g.rows + (size_t)s_ids[j + 1] * g.row_stride, r1);
+      }
+      const float d0 = dist8<LPRO>(g, c, r0, cn, s_norm[j]);
+      bool v = fbits(d0 * g.alpha) < cdb; // hnsw.rs:585
+      if (two) {
+        const float d1 = dist8<LPRO>(g, c, r1, cn, s_norm[j + 1]);
+        v = v || fbits(d1 * g.alpha) < cdb;
+      }
+      viol = viol || v;
+      evals += (u64)((__popcll(open) >> 3) << (two ? 1 : 0));
     }
     // (3) the survivors, in candidate order
     u64 sv = ballot(have && !viol && t == 0);
