@@ -367,21 +367,25 @@ static uint32_t vis_slots_for(const hny_builder *b, uint32_t rcap) {
 }
 // Short rows (<= 512 B, walk_layer_short): the LDS visited table of 16-bit remainders.  As many buckets as keep
 // the walk's occupancy: 10 KB of LDS per wave at 4 waves per SIMD (f32: 896 buckets; 640: +2 %, 1 024: +5 % walk
-// time at 4M x 128), 7 KB at 5 (binary codes: 512 buckets; 640 and 768 were 3 % / 1.5 % slower at C5, 4 096 waves
-// instead of 5 120 9 %) — and only while a remainder fits 16 bits (2^k / buckets < 65 535, n < 2^28).
+// time at 4M x 128), 6.25 KB at 6 (binary codes: 448 buckets and 6 144 resident waves; at 5 waves per SIMD 512
+// buckets were best, 640 / 768 3 % / 1.5 % slower) — and only while a remainder fits 16 bits (2^k / buckets
+// < 65 535, n < 2^28).
 // HNY_VIS_BUCKETS overrides (0 = bitset only).
 static void vis_buckets_for(const hny_builder *b, WalkArgs &w) {
   w.vis_buckets = w.vis_magic = w.vis_shift = w.vis_smask = 0;
   if ((size_t)b->g.n16 * 16 > 512 || w.vis_slots || w.res_global || w.rcap > 128 || w.eps_cap > 64) return;
   const size_t fixed = hnyk_walk_lds_bytes(w.rcap, w.eps_cap);
-  const size_t budget = (b->shape.nch == 1 && b->o.metric >= HNY_HAMMING) ? 7168 : 10240;
+  const size_t budget = (b->shape.nch == 1 && b->o.metric >= HNY_HAMMING) ? 6400 : 10240;
   int nb = fixed + 1024 <= budget ? (int)((budget - fixed) / 8 / 64 * 64) : 0;
   const char *e = getenv("HNY_VIS_BUCKETS");
   if (e && *e) nb = std::max(0, std::min(4096, atoi(e) / 2 * 2));
   if (nb < 64) return;
   uint32_t k = 1;
   while (k < 28 && (1ull << k) < (uint64_t)std::max<uint32_t>(b->g.n, 2)) k++;
-  if ((1ull << k) < (uint64_t)b->g.n || ((1ull << k) - 1) / (uint64_t)nb + 1 >= 65535) return;
+  if ((1ull << k) < (uint64_t)b->g.n) return;
+  if (!(e && *e)) // a larger index: more buckets (fewer resident waves) before giving the table up
+    while (((1ull << k) - 1) / (uint64_t)nb + 1 >= 65535 && fixed + (size_t)(nb + 64) * 8 <= 12288) nb += 64;
+  if (((1ull << k) - 1) / (uint64_t)nb + 1 >= 65535) return;
   w.vis_buckets = (u32)nb;
   uint32_t lg = 0;
   while ((2u << lg) <= (uint32_t)nb) lg++;
@@ -909,7 +913,7 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
                 b->bmax, o.M0, b->max_ops, HNY_SEQ_BITS, (uint32_t)((1ull << (HNY_SEQ_BITS - 1)) / std::max(o.M0, 2 * o.M) / 2));
   // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (5 for binary codes <= 1 KB, see k_walk)
   b->walk_slots = (uint32_t)std::min<int64_t>(
-      std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 && o.metric >= HNY_HAMMING ? 5120 : 4096)), 65536);
+      std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 && o.metric >= HNY_HAMMING ? 6144 : 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
   b->vis_slots_env = env_int("HNY_VIS_SLOTS", -1);

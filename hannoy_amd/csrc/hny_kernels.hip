@@ -1753,12 +1753,13 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
 #ifndef HNY_WALK_WPE
 #define HNY_WALK_WPE 4
 #endif
-// binary codes of at most 1 KB (NCH == 1; no LDS visited table there, so LDS allows it): the
-// specialised BUILD kernels fit ~96 VGPRs and run 5 waves per SIMD (Hamming 1024-bit: walk 0.344 ->
-// 0.310 s; 6 would spill; the Reader's variant carries the exhaustive fallback and spills at 96: 4 waves).  The f32 kernels of that row size spill 22 VGPRs at 96 and gain nothing
-// from the fifth wave; the general kernels already spill at 4.
+// binary codes of at most 1 KB (NCH == 1): the specialised BUILD kernels run 6 waves per SIMD in 79 VGPRs (two
+// spilled) — the walk on 128-B codes is bound by instruction issue and latency, and with the visited set in LDS
+// the sixth wave pays (C5 walk 0.401 -> 0.377 s with 6 144 resident waves and 448 buckets; 7 waves: 0.382, 9
+// spilled VGPRs and too little LDS left for the table).  The Reader's variant carries the exhaustive fallback
+// and spills at 96: 4 waves; the f32 kernels of that row size need 128 VGPRs; the general kernels spill at 4.
 #ifndef HNY_WALK_WPE_SMALL
-#define HNY_WALK_WPE_SMALL 5
+#define HNY_WALK_WPE_SMALL 6
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, int RC = 0>
 __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
