@@ -696,11 +696,12 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   if (o.dim == 0) return fail(HNY_ERR_INVALID_DIM, "dim must be > 0");
   if (o.M == 0 || o.M0 < o.M) return fail(HNY_ERR_INVALID_ARG, "need 1 <= M <= M0");
   if (o.M0 > HNY_BIG_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_BIG_CAP);
-  // 64 < M0 <= HNY_BIG_CAP: lists are walked 64 slots at a time and the workgroup kernels hold them
-  // whole (incremental builds: k_fill_gaps_wg); strict mode's one-wave kernels keep one lane per slot
+  // 64 < M0 <= HNY_BIG_CAP: lists are walked 64 slots at a time; the workgroup kernels hold them whole (incremental
+  // builds: k_fill_gaps_wg), strict mode's one-wave kernels (k_prune, k_apply) take them 64 slots at a time —
+  // for fresh builds and loaded graphs; a strict-mode UPDATE of such lists (k_fill_gaps: one lane per slot) is refused
   const bool bigcap = o.M0 > HNY_MAX_CAP;
-  if (bigcap && o.x86_order)
-    return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: builds in the wave order only (no x86_order)", o.M0, HNY_MAX_CAP);
+  if (bigcap && o.x86_order && inc && !inc->load_only)
+    return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: incremental builds in the wave order only (no x86_order)", o.M0, HNY_MAX_CAP);
   if (o.ef_construction == 0 || o.ef_construction > HNY_MAX_EF)
     return fail(HNY_ERR_UNSUPPORTED, "ef_construction %u outside [1, %d]", o.ef_construction,
                 HNY_MAX_EF);
@@ -926,8 +927,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     // the workgroup prune kernels carry their own wave-order arithmetic: strict mode and very long
     // rows use the single-wave kernels, which all go through dist_rows
     b->wave_prune_only = b->shape.nch > 8 || o.x86_order; // the one-wave prune: strict mode, rows beyond 8 KB
-    if (bigcap && b->wave_prune_only)
-      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d needs the workgroup prune kernels (rows <= 8 KB, wave order)",
+    if (bigcap && b->wave_prune_only && inc && !inc->load_only)
+      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: an incremental build needs the workgroup kernels (rows <= 8 KB, wave order)",
                   o.M0, HNY_MAX_CAP);
   }
 

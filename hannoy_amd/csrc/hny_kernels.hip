@@ -3008,6 +3008,12 @@ __global__ __launch_bounds__(64, 4) void k_nns_linear(GraphDev g, NnsArgs a) {
 // list/sel keys: dist bits << 32 | slot.  `exists i in S: bits(d(c,i)*alpha) < bits(dq)` does not
 // depend on evaluation order, so S is tested RPI rows at a time with an early exit per chunk.
 // ---------------------------------------------------------------------------------------------
+// LDS entries of the one-wave prune / add_link kernels' per-list arrays: the larger list capacity, in whole waves
+// (one lane per slot up to 64; strict mode and rows beyond 8 KB take longer lists 64 slots at a time)
+__host__ __device__ inline u32 wave_capmax(const GraphDev &g) {
+  const u32 c = g.M0 > g.M ? g.M0 : g.M;
+  return c <= (u32)HNY_MAX_CAP ? (u32)HNY_MAX_CAP : (c + 63u) / 64u * 64u;
+}
 template <int LPR, int NCH>
 __device__ int wave_prune(const GraphDev &g, const u64 *list, int n, int cap, u64 *S, u32 *s_ids,
                           float *tmp_d, u64 &evals) {
@@ -3052,8 +3058,9 @@ __global__ __launch_bounds__(64) void k_prune(GraphDev g, PruneArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *list = reinterpret_cast<u64 *>(smem);
   u64 *S = list + a.rcap;
-  u32 *s_ids = reinterpret_cast<u32 *>(S + HNY_MAX_CAP);
-  float *tmp_d = reinterpret_cast<float *>(s_ids + HNY_MAX_CAP);
+  const u32 capmax = wave_capmax(g);
+  u32 *s_ids = reinterpret_cast<u32 *>(S + capmax);
+  float *tmp_d = reinterpret_cast<float *>(s_ids + capmax);
   const int ln = threadIdx.x;
   u64 evals = 0;
   for (u32 m = a.lo + blockIdx.x; m < a.hi; m += gridDim.x) {
@@ -3063,7 +3070,7 @@ __global__ __launch_bounds__(64) void k_prune(GraphDev g, PruneArgs a) {
     int s_len = wave_prune<LPR, NCH>(g, list, n, (int)a.cap, S, s_ids, tmp_d, evals);
     u64 *out = a.sel + (size_t)m * a.sel_stride + (size_t)(a.batch_level - a.layer) * (a.cap_sel + 1);
     if (ln == 0) out[0] = (u64)s_len;
-    if (ln < s_len) out[1 + ln] = S[ln];
+    for (int e = ln; e < s_len; e += 64) out[1 + e] = S[e];
     WSYNC();
   }
   if (ln == 0 && evals) atomicAdd(&g.stats[ST_EVALS_PRUNE], evals);
@@ -3754,11 +3761,15 @@ template <int LPR, int NCH, int SP>
 __global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
   GraphDev g = g_in;
   specialize<SP>(g);
-  __shared__ u64 lk[HNY_MAX_CAP];     // the node's list: dist bits << 32 | slot
-  __shared__ u64 sorted[HNY_MAX_CAP];
-  __shared__ u64 S[HNY_MAX_CAP];
-  __shared__ u32 s_ids[HNY_MAX_CAP];
-  __shared__ float tmp_d[HNY_MAX_CAP];
+  // (lists of more than 64 slots — strict mode with M0 up to HNY_BIG_CAP, the reference's fuzz pair (16, 768) in
+  // the x86 order — are held whole and taken 64 slots at a time)
+  extern __shared__ __align__(16) unsigned char smem[];
+  const u32 capmax = wave_capmax(g);
+  u64 *lk = reinterpret_cast<u64 *>(smem); // the node's list: dist bits << 32 | slot
+  u64 *sorted = lk + capmax;
+  u64 *S = sorted + capmax;
+  u32 *s_ids = reinterpret_cast<u32 *>(S + capmax);
+  float *tmp_d = reinterpret_cast<float *>(s_ids + capmax);
   const int ln = threadIdx.x;
   const u32 n_seg = *a.n_seg;
   u64 evals = 0;
@@ -3799,7 +3810,7 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
         continue;
       }
     }
-    if (ln < cnt) lk[ln] = ((u64)fbits(dist[ln]) << 32) | ids[ln];
+    for (int e = ln; e < cnt; e += 64) lk[e] = ((u64)fbits(dist[e]) << 32) | ids[e];
     WSYNC();
     for (u32 i = i0; i < a.n_ops; i++) {
       const u64 key = a.keys[i];
@@ -3811,16 +3822,18 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
         cnt++;
         WSYNC();
       } else if (!frozen) { // :547-552 full: self-prune, the new link is dropped
-        u64 mine = ln < cnt ? lk[ln] : 0ull;
-        int rk = 0;
-        for (int j = 0; j < cnt; j++) {
-          u64 o = lk[j];
-          rk += (o < mine || (o == mine && j < ln)) ? 1 : 0;
+        for (int e = ln; e < cnt; e += 64) { // stable rank sort by (distance bits, slot), ties in list order
+          const u64 mine = lk[e];
+          int rk = 0;
+          for (int j = 0; j < cnt; j++) {
+            const u64 o = lk[j];
+            rk += (o < mine || (o == mine && j < e)) ? 1 : 0;
+          }
+          sorted[rk] = mine;
         }
-        if (ln < cnt) sorted[rk] = mine;
         WSYNC();
         int s_len = wave_prune<LPR, NCH>(g, sorted, cnt, (int)cap, S, s_ids, tmp_d, evals);
-        if (ln < s_len) lk[ln] = S[ln];
+        for (int e = ln; e < s_len; e += 64) lk[e] = S[e];
         cnt = s_len;
         // a full list that prunes to itself can never change again: every later add_link would
         // redo the same prune with the same outcome
@@ -3828,10 +3841,10 @@ __global__ __launch_bounds__(64) void k_apply(GraphDev g_in, ApplyArgs a) {
         WSYNC();
       }
     }
-    if ((u32)ln < cap) {
-      bool on = ln < cnt;
-      ids[ln] = on ? (u32)(lk[ln] & 0xFFFFFFFFull) : HNY_SENT;
-      dist[ln] = on ? __uint_as_float((u32)(lk[ln] >> 32)) : 0.f;
+    for (u32 e = (u32)ln; e < cap; e += 64) {
+      const bool on = (int)e < cnt;
+      ids[e] = on ? (u32)(lk[e] & 0xFFFFFFFFull) : HNY_SENT;
+      dist[e] = on ? __uint_as_float((u32)(lk[e] >> 32)) : 0.f;
     }
     if (ln == 0) *cntp = (u32)cnt | (frozen ? 0x80000000u : 0u);
     WSYNC();
@@ -4555,7 +4568,8 @@ struct Hot {
   template <int L, int C>
   struct Apply {
     static hipError_t run(const GraphDev &g, const ApplyArgs &a, int grid, hipStream_t st) {
-      hipLaunchKernelGGL((k_apply<L, C, SP>), dim3(grid), dim3(64), 0, st, g, a);
+      const size_t lds = (size_t)wave_capmax(g) * (8 + 8 + 8 + 4) + 64 * 4;
+      hipLaunchKernelGGL((k_apply<L, C, SP>), dim3(grid), dim3(64), lds, st, g, a);
       return hipGetLastError();
     }
   };
@@ -4595,7 +4609,7 @@ struct NnsLinearLauncher {
 template <int L, int C>
 struct PruneLauncher {
   static hipError_t run(const GraphDev &g, const PruneArgs &a, int grid, hipStream_t st) {
-    size_t lds = (size_t)a.rcap * 8 + HNY_MAX_CAP * (8 + 4 + 4);
+    size_t lds = (size_t)a.rcap * 8 + (size_t)wave_capmax(g) * (8 + 4) + 64 * 4;
     hipLaunchKernelGGL((k_prune<L, C>), dim3(grid), dim3(64), lds, st, g, a);
     return hipGetLastError();
   }

@@ -60,8 +60,8 @@ typedef struct {
   uint32_t dim;              /* user dimensions (binary codecs pad to 64, binary.rs:80-94) */
   uint32_t M, M0;            /* defaults 16, 32 (README.md:51, python.rs:120).  1 <= M <= M0 <= 1024
                               * in the wave order — fresh and incremental builds,
-                              * loading / searching a stored graph; M0 <= 64 in strict mode
-                              * (x86_order), whose one-wave kernels keep one lane per neighbour slot.
+                              * loading / searching a stored graph; strict mode
+                              * (x86_order) too, except for an incremental build over lists of more than 64 slots.
                               * That covers every pair the reference's Python API offers ((4,8) ..
                               * (32,64), python.rs:280) and the pair of the reference's fuzz test,
                               * M = 16, M0 = 768 with incremental builds (src/tests/fuzz.rs:86-87,143).

@@ -130,8 +130,8 @@ def test_argument_validation(hny):
         hny.build(items, M=16, M0=2048)  # beyond HNY_BIG_CAP = 1024
     assert e.value.code == -5
     with pytest.raises(hny.HannoyError) as e:
-        hny.build(items, M=16, M0=128, x86_order=True)  # 64 < M0 <= 1024: wave-order fresh builds only
-    assert e.value.code == -5
+        hny.build(items, M=16, M0=128, x86_order=True)  # accepted since round 4 (strict mode, lists beyond 64 slots):
+    assert e.value.code == -6                            # passes validation and stops at "no HIP device" here
     bad = hny.ItemSet(hny.EUCLIDEAN, 16, items.ids, items.codes, items.headers)  # stride < 16*4
     with pytest.raises(hny.HannoyError) as e:
         hny.build(bad)

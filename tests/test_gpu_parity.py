@@ -745,6 +745,27 @@ def test_strict_mode_build_equals_reference_faithful_oracle(orc, hny, metric, n,
     _same_graph(g, o)
 
 
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,frac,bmax,lvM", [(1, 1200, 40, 16, 768, 64, 0.0, 1, 16),   # the fuzz pair
+                                                                 (1, 900, 30, 16, 96, 48, 0.0, 1, 16),    # SSE path
+                                                                 (0, 1500, 64, 80, 160, 64, 0.1, 64, 4),  # M > 64 too
+                                                                 (2, 700, 24, 8, 100, 32, 0.25, 32, 8),
+                                                                 (0, 600, 2100, 8, 70, 24, 0.1, 64, 8)])  # rows > 8 KB
+def test_strict_mode_lists_beyond_64_slots_equal_x86_oracle(orc, hny, metric, n, dim, M, M0, ef, frac, bmax, lvM):
+    """Strict mode (x86 summation order) with lists of more than 64 slots — the reference's fuzz pair
+    build::<16, 768> (src/tests/fuzz.rs:86-87) in the reference's own arithmetic: the one-wave prune / add_link
+    kernels take such lists 64 slots at a time (round 4; refused before).  The same kernels serve rows beyond 8 KB
+    in the wave order (last case)."""
+    rng = np.random.default_rng(3 * n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds, items = _mk(orc, hny, metric, vecs, draw_levels(n, lvM, seed=n))
+    strict = dim < 2048
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86 if strict else orc.ORDER_WAVE, batch_frac=frac,
+                  batch_max=0 if bmax == 1 else bmax)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, batch_frac=frac, batch_max=bmax, x86_order=strict)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
+
+
 def test_randomized_parameter_sweep(orc, hny):
     """40 seeded random configurations (all metrics, odd dims, M == M0, ef below M0, ef = 1, many
     entry points, duplicates, tiny inputs, sequential and batched schedules): GPU == oracle."""
@@ -1554,14 +1575,19 @@ def test_m_beyond_64_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0,
 
 
 def test_m0_limits_are_refused_loudly(orc, hny):
-    """include/hannoy_amd.h: M <= M0 <= 1024 in the wave order, M0 <= 64 in strict mode:
-    HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
+    """include/hannoy_amd.h: M <= M0 <= 1024 (strict mode too since round 4: fresh builds; a strict-mode UPDATE of
+    lists beyond 64 slots stays refused): HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
     v = np.random.default_rng(1).uniform(-1, 1, (500, 32)).astype(np.float32)
     items = hny.ItemSet.from_f32(hny.COSINE, v)
-    for kw in (dict(M=16, M0=1025), dict(M=1025, M0=1025), dict(M=80, M0=160, x86_order=True), dict(M=16, M0=96, x86_order=True)):
+    for kw in (dict(M=16, M0=1025), dict(M=1025, M0=1025)):
         with pytest.raises(hny.HannoyError) as e:
             hny.build(items, ef_construction=32, **kw)
         assert e.value.code == -5
+    g = hny.build(items, M=16, M0=96, ef_construction=32, x86_order=True, batch_max=1)
+    with pytest.raises(hny.HannoyError) as e:
+        hny.build_incremental(items, g, to_insert=np.arange(10, dtype=np.uint32), to_delete=np.arange(10, 20, dtype=np.uint32),
+                              M=16, M0=96, ef_construction=32, x86_order=True, batch_max=1)
+    assert e.value.code == -5
 
 
 def test_kat9_reference_snapshots_on_the_gpu(orc, hny):
