@@ -11,7 +11,7 @@ typedef unsigned int u32;
 #define HNY_SENT 0xFFFFFFFFu      // empty neighbour slot
 #define HNY_MAX_CAP 64            // max(M, M0) of the one-lane-per-slot kernels (incremental builds, strict mode)
 #define HNY_BIG_CAP 1024          // M0 of fresh builds / loaded graphs: lists are walked 64 slots at a time
-#define HNY_MAX_EPS 2048          // max entry points (every item of a small all-level-0 index is one)
+#define HNY_MAX_EPS 8192          // max entry points (every item of a small all-level-0 index is one): 32 KB of LDS ids
 #define HNY_POOL_CAP 128          // tie pool (DESIGN.md "candidate heap")
 #define HNY_MAX_EF 65535         // ef_construction: result sets of ef + 1 entries, in the walk's LDS up to 4 096, in HBM beyond
 #define HNY_OP_INVALID 0xFFFFFFFFFFFFFFFFull

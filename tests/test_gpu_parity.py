@@ -986,7 +986,7 @@ def test_levels_up_to_14(orc, hny):
     _same_graph(gg2, og2)
 
 
-@pytest.mark.parametrize("metric,n,dim", [(1, 300, 16), (0, 700, 768), (3, 130, 256)])
+@pytest.mark.parametrize("metric,n,dim", [(1, 300, 16), (0, 700, 768), (3, 130, 256), (1, 3000, 16)])
 def test_every_item_an_entry_point(orc, hny, metric, n, dim):
     """A small index whose items all drew level 0 (M=32, n=100: 4 % of the seeds) has every item as an
     entry point (hnsw.rs:278-285): all of them seed every walk.  Fresh build, search, and an
