@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box comparison of several variants (library builds and/or environment knobs), ROUNDS alternating passes:
-#   VARIANTS='base||;tab2048|HNY_SHORT_TAB=2048 HNY_WALK_SLOTS=3584|hannoy_amd/libhannoy_amd_tab.so' CFGS="c5 c4s" bash scripts/r4_variants.sh
+#   VARIANTS='base||;nb512|HNY_VIS_BUCKETS=512|;w7|HNY_WALK_SLOTS=7168|hannoy_amd/libhannoy_amd_w7.so' CFGS="c5 c4s" bash scripts/r4_variants.sh
 # each variant: name|environment assignments|library (empty = the in-tree build)
 mkdir -p gpurun_out/r4_var
 A="--no-cpu --no-recall --queries 0 --alt-data none --steps ${STEPS:-2} --warmup 1"
