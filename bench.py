@@ -297,6 +297,7 @@ def main():
         t0 = time.perf_counter()
         g = None
         for _ in range(steps):
+            g = None  # the previous build's records are released before the next export (hny_graph_free)
             g = step()
         if world > 1:
             dist.barrier()
