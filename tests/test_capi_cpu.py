@@ -277,3 +277,39 @@ def test_level_draws_match_oracle_rng(hny, orc):
     """hny_draw_levels == the oracle's restated StdRng::seed_from_u64 + WeightedIndex draws."""
     for seed, M in ((42, 16), (0, 3), (2 ** 63 + 5, 32), (7, 4)):
         assert np.array_equal(hny.draw_levels(seed, M, 50000), orc.draw_levels(M, 50000, seed_u64=seed))
+
+
+def test_short_row_visited_table_arithmetic():
+    """The arithmetic behind VisB (hny_kernels.hip), restated: slot id -> bijection of [0, 2^k) -> (bucket, remainder)
+    by a multiply-shift division that must be exact, and back (the Reader's flush reconstructs ids from the table).
+    Constants read from the sources, so a change there is checked here."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "hannoy_amd", "csrc", "hny_kernels.hip")).read()
+    mul = int(re.search(r"#define HNY_VISB_MUL (0x[0-9A-Fa-f]+)u", src).group(1), 16)
+    inv = int(re.search(r"#define HNY_VISB_INV (0x[0-9A-Fa-f]+)u", src).group(1), 16)
+    assert mul & 1 and (mul * inv) % (1 << 32) == 1
+    rng = np.random.default_rng(0)
+    for n, nb in ((9000, 64), (5_000_000, 448), (10_000_000, 896), (1 << 24, 448), (1 << 25, 896), (3, 64), (1 << 28, 4096)):
+        k = 1
+        while k < 28 and (1 << k) < max(n, 2):
+            k += 1
+        smask = (1 << k) - 1
+        lg = 0
+        while (2 << lg) <= nb:
+            lg += 1
+        shift = 31 + lg
+        magic = (1 << shift) // nb + 1
+        assert magic < (1 << 32)
+        ids = np.unique(np.concatenate([rng.integers(0, n, 200_000), [0, n - 1]])).astype(np.uint64)
+        sid = (ids * mul) & smask
+        q = (sid * magic) >> shift                     # what the kernel computes (64-bit product)
+        assert np.array_equal(q, sid // nb)            # == sid div nb, exactly
+        bk = sid - q * nb
+        assert bk.max() < nb
+        back = (((q * nb + bk) & 0xFFFFFFFF) * inv) & smask
+        assert np.array_equal(back, ids)               # bucket and remainder give the id back
+        assert len(np.unique(sid)) == len(ids)         # a bijection on the ids
+        if (smask // nb) + 1 < 65535:
+            assert (q + 1).max() <= 65535              # remainder + 1 fits 16 bits (0 = empty)
