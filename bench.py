@@ -24,6 +24,7 @@ a port of the reference algorithm — the real hannoy crate cannot be built here
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -47,7 +48,8 @@ def parse():
     p.add_argument("--M", type=int, default=16)
     p.add_argument("--M0", type=int, default=0)
     p.add_argument("--ef", type=int, default=100)
-    p.add_argument("--data", default="clustered", choices=["clustered", "overlap", "manifold", "uniform"])
+    p.add_argument("--data", default="clustered",
+                   help="clustered | overlap | manifold | uniform | lat<k>[i<iso>][s<spread>] (gen_data)")
     p.add_argument("--alt-data", default=None, choices=["overlap", "uniform", "clustered", "none"],
                    help="second distribution measured in the same run (value_alt / roofline_alt / recall_at_10_alt): "
                         "one warm-up + --alt-steps builds.  Default: overlap for the headline C2 workload, else none")
@@ -146,21 +148,29 @@ def gen_data(torch, n, dim, kind, seed, device, queries=False):
     gn = g2 if queries else g  # the structure (centres, basis) always comes from `g`
     if kind == "uniform":  # reference-style U(-1,1) (src/tests/mod.rs:133-136)
         return torch.rand((n, dim), generator=gn, device=device, dtype=torch.float32) * 2 - 1
-    if kind in ("overlap", "manifold"):
+    m_lat = re.fullmatch(r"lat(\d+)(?:i([0-9.]+))?(?:s([0-9.]+))?", kind)
+    if kind in ("overlap", "manifold") or m_lat:
         # embedding-like: 1 024 OVERLAPPING clusters on a 32-d manifold embedded in `dim` dimensions
         # (latent centres N(0, 1), points centre + 0.5 N(0, 1): the spread inside a cluster is half the
         # spread of the centres, so neighbourhoods cross cluster borders) + 0.05 isotropic noise
         # ("manifold": 0.01 — at 5M / 10M points the manifold is populated so densely that 0.05 of isotropic
         # noise per component, not the manifold, decides who the ten nearest neighbours are)
+        # "lat<k>[i<iso>][s<spread>]": the same family with a k-d manifold (the local intrinsic dimension of real
+        # embedding sets is 10 - 20, not 32), iso noise (default 0.01) and cluster spread (default 0.5) as given
         iso = 0.05 if kind == "overlap" else 0.01
         k = min(32, dim)
+        spread = 0.5
+        if m_lat:
+            k = min(int(m_lat.group(1)), dim)
+            iso = float(m_lat.group(2)) if m_lat.group(2) else 0.01
+            spread = float(m_lat.group(3)) if m_lat.group(3) else 0.5
         centres = torch.randn((1024, k), generator=g, device=device, dtype=torch.float32)
         basis = torch.linalg.qr(torch.randn((dim, k), generator=g, device=device, dtype=torch.float32))[0].T
         which = torch.randint(0, 1024, (n,), generator=gn, device=device)
         out = torch.empty((n, dim), device=device, dtype=torch.float32)
         for lo in range(0, n, 1 << 18):  # in slices: bounded temporaries
             hi = min(n, lo + (1 << 18))
-            z = centres[which[lo:hi]] + 0.5 * torch.randn((hi - lo, k), generator=gn, device=device)
+            z = centres[which[lo:hi]] + spread * torch.randn((hi - lo, k), generator=gn, device=device)
             out[lo:hi] = z @ basis + iso * torch.randn((hi - lo, dim), generator=gn, device=device)
         return out
     # 1024-centre Gaussian mixture, centres U(-1,1), sigma 0.15: well separated
@@ -171,24 +181,59 @@ def gen_data(torch, n, dim, kind, seed, device, queries=False):
     return centres[which] + 0.15 * torch.randn((n, dim), generator=gn, device=device, dtype=torch.float32)
 
 
-def brute_force_topk(torch, metric, data, queries, k):
-    """Exact top-k under the reference's metric definition (plumbing, torch on the GPU)."""
-    out = []
-    for q0 in range(0, queries.shape[0], 256):
-        q = queries[q0:q0 + 256]
+def brute_force_topk(torch, metric, data, queries, k, chunk=1 << 20):
+    """Exact top-k under the reference's metric definition (plumbing, torch on the GPU).
+
+    The items are scored in pieces of `chunk` rows and the per-piece top-(k+32) merged, then re-ranked in f64.
+    Rounds 1-4 scored all items with ONE f32 GEMM per 256 queries: beyond 2^31 score elements (n > 8.39 M, i.e.
+    C4's 10M x 128) that GEMM / top-k returns garbage for part of the matrix on this stack, and the "truth" held
+    ~12 % wrong neighbours — the recall plateau of 0.84 - 0.88 "whatever the beam width" that rounds 3-4 reported
+    for every 10M index, GPU- or CPU-built, was this function (scripts/r5_truth_diag.py: the same index scores
+    1.0 against an exact f64 truth and 0.8799 against the old one)."""
+    nq, n = queries.shape[0], data.shape[0]
+    kk = min(n, k + 32)
+    dev = data.device
+    if metric == "cosine":
+        qn = queries / queries.norm(dim=1, keepdim=True)
+    elif metric == "hamming":
+        qn = (queries > 0).float()
+    else:
+        qn = queries
+    best_v = torch.full((nq, 0), 0.0, device=dev)
+    best_i = torch.zeros((nq, 0), dtype=torch.int64, device=dev)
+    for lo in range(0, n, chunk):
+        xb = data[lo:lo + chunk]
         if metric == "cosine":
-            s = (q / q.norm(dim=1, keepdim=True)) @ (data / data.norm(dim=1, keepdim=True)).T
-            out.append(torch.topk(s, k, dim=1).indices)
+            sc = -(qn @ (xb / xb.norm(dim=1, keepdim=True)).T)  # ascending = closer, like the distances below
         elif metric == "euclidean":
-            d = torch.cdist(q, data)
-            out.append(torch.topk(d, k, dim=1, largest=False).indices)
+            sc = torch.cdist(qn, xb)
         elif metric == "manhattan":
-            d = torch.cdist(q, data, p=1)
-            out.append(torch.topk(d, k, dim=1, largest=False).indices)
+            sc = torch.cdist(qn, xb, p=1)
         else:  # hamming on the Binary codec bits (x > 0)
-            qb, db = (q > 0).float(), (data > 0).float()
-            d = qb @ (1 - db).T + (1 - qb) @ db.T
-            out.append(torch.topk(d, k, dim=1, largest=False).indices)
+            db = (xb > 0).float()
+            sc = qn @ (1 - db).T + (1 - qn) @ db.T
+        v, i = torch.topk(sc, min(kk, xb.shape[0]), dim=1, largest=False)
+        cv, ci = torch.cat([best_v, v], 1), torch.cat([best_i, i + lo], 1)
+        o = torch.topk(cv, min(kk, cv.shape[1]), dim=1, largest=False).indices
+        best_v, best_i = torch.gather(cv, 1, o), torch.gather(ci, 1, o)
+    if metric == "hamming":  # integer distances: exact already; ties stay in (distance, id) order
+        key = best_v.double() * float(n) + best_i.double()
+        o = torch.argsort(key, dim=1)[:, :k]
+        return torch.gather(best_i, 1, o).cpu().numpy()
+    # exact re-rank of the kk survivors in f64 (f32 scores of neighbours 10 and 11 can tie at 10M items)
+    out = []
+    for q0 in range(0, nq, 64):
+        cand = best_i[q0:q0 + 64]
+        xd = data[cand.reshape(-1)].double().reshape(cand.shape[0], cand.shape[1], -1)
+        qd = queries[q0:q0 + 64].double()[:, None, :]
+        if metric == "cosine":
+            d = -(xd * qd).sum(2) / (xd.norm(dim=2) * qd.norm(dim=2))
+        elif metric == "euclidean":
+            d = ((xd - qd) ** 2).sum(2)
+        else:
+            d = (xd - qd).abs().sum(2)
+        o = torch.argsort(d, dim=1, stable=True)[:, :k]
+        out.append(torch.gather(cand, 1, o))
     return torch.cat(out).cpu().numpy()
 
 

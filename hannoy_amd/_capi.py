@@ -76,7 +76,11 @@ class BuildOpts(C.Structure):
                 ("cancel", CANCEL_FN), ("cancel_ctx", C.c_void_p),
                 ("progress", PROGRESS_FN), ("progress_ctx", C.c_void_p),
                 ("batch_frac", C.c_double), ("batch_max", C.c_uint32), ("device", C.c_int32),
-                ("x86_order", C.c_int32), ("n_gpus", C.c_int32), ("devices", C.POINTER(C.c_int32))]
+                ("x86_order", C.c_int32), ("n_gpus", C.c_int32), ("devices", C.POINTER(C.c_int32)),
+                ("schedule", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+SCHED_NO_SHUFFLE, SCHED_LEVEL_ORDER_ID, SCHED_UPDATE_NO_RAMP = 1, 2, 4  # hny_build_opts.schedule (HNY_SCHED_*)
 
 
 class Items(C.Structure):
@@ -384,8 +388,10 @@ class ItemSet:
 
 
 def make_opts(metric, dim, M=16, M0=32, ef_construction=100, alpha=1.0, seed=42, batch_frac=0.0,
-              batch_max=0, device=-1, cancel=None, progress=None, x86_order=False, n_gpus=0, devices=None):
+              batch_max=0, device=-1, cancel=None, progress=None, x86_order=False, n_gpus=0, devices=None,
+              schedule=0):
     o = BuildOpts()
+    o.schedule = int(schedule)
     o.metric, o.dim, o.M, o.M0 = metric, dim, M, M0
     o.ef_construction, o.alpha, o.seed = ef_construction, alpha, seed
     o.batch_frac, o.batch_max, o.device = batch_frac, batch_max, device

@@ -43,18 +43,14 @@ int fail(int code, const char *fmt, ...) {
 } // namespace
 // error reporting for the other host translation units (hny_lmdb.cpp)
 int hny_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
-// HNY_LEVEL_ORDER=id: items of one level inserted in ascending id order (rounds 1-2) instead of the order
-// Rust's sort_unstable_by leaves them in (hny_rust_sort.h)
-// batches of more than one member: the items of a level group in a fixed pseudo-random order (hny_rust_sort.h);
-// HNY_NO_SHUFFLE=1: consecutive runs of the reference's order (rounds 1-2)
-static bool shuffle_groups(uint32_t batch_max) {
-  const char *e = getenv("HNY_NO_SHUFFLE");
-  return batch_max != 1u && !(e && atoi(e) != 0);
+// hny_build_opts.schedule (HNY_SCHED_*): LEVEL_ORDER_ID = items of one level inserted in ascending id order
+// (rounds 1-2) instead of the order Rust's sort_unstable_by leaves them in (hny_rust_sort.h); batches of more than
+// one member take the items of a level group in a fixed pseudo-random order (hny_rust_sort.h) unless NO_SHUFFLE
+// asks for consecutive runs of the reference's order (rounds 1-2)
+static bool shuffle_groups(const hny_build_opts &o, uint32_t batch_max) {
+  return batch_max != 1u && !(o.schedule & HNY_SCHED_NO_SHUFFLE);
 }
-static bool level_order_by_id() {
-  const char *e = getenv("HNY_LEVEL_ORDER");
-  return e && (e[0] == 'i' || e[0] == 'I');
-}
+static bool level_order_by_id(const hny_build_opts &o) { return (o.schedule & HNY_SCHED_LEVEL_ORDER_ID) != 0; }
 namespace {
 
 double now_s() {
@@ -697,6 +693,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   if (o.metric < 0 || o.metric > HNY_BQ_MANHATTAN) return fail(HNY_ERR_INVALID_ARG, "bad metric");
   if (o.dim == 0) return fail(HNY_ERR_INVALID_DIM, "dim must be > 0");
   if (o.M == 0 || o.M0 < o.M) return fail(HNY_ERR_INVALID_ARG, "need 1 <= M <= M0");
+  if ((o.schedule & ~(uint32_t)(HNY_SCHED_NO_SHUFFLE | HNY_SCHED_LEVEL_ORDER_ID | HNY_SCHED_UPDATE_NO_RAMP)) || o.reserved_)
+    return fail(HNY_ERR_INVALID_ARG, "unknown hny_build_opts.schedule bits 0x%x", o.schedule);
   if (o.M0 > HNY_BIG_CAP) return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d", o.M0, HNY_BIG_CAP);
   // 64 < M0 <= HNY_BIG_CAP: lists are walked 64 slots at a time; the workgroup kernels hold them whole (incremental
   // builds: k_fill_gaps_wg), strict mode's one-wave kernels (k_prune, k_apply) take them 64 slots at a time —
@@ -780,8 +778,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     else
       draw_levels(o.seed, o.M, n, lv.data());
     for (uint32_t s = 0; s < n; s++) levels.push_back({s, lv[s]});
-    hny_rust_sort::sort_levels(levels, level_order_by_id()); // hnsw.rs:268, ties as the reference leaves them
-    if (shuffle_groups(b->bmax)) hny_rust_sort::shuffle_level_groups(levels);
+    hny_rust_sort::sort_levels(levels, level_order_by_id(o)); // hnsw.rs:268, ties as the reference leaves them
+    if (shuffle_groups(o, b->bmax)) hny_rust_sort::shuffle_level_groups(levels);
     b->max_level = n ? levels[0].second : 0;
     for (uint32_t s = 0; s < n; s++)
       if (lv[s] == b->max_level) b->entry_points.push_back(s);
@@ -835,8 +833,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     if (!del_eps.empty() && n_new != n_old) max_level = 0; // :261-263
     for (uint32_t s = 0; s < n; s++)
       if (in_new[s] && !inc->load_only) levels.push_back({s, (uint8_t)max_level}); // :267
-    hny_rust_sort::sort_levels(levels, level_order_by_id()); // :268
-    if (shuffle_groups(b->bmax)) hny_rust_sort::shuffle_level_groups(levels);
+    hny_rust_sort::sort_levels(levels, level_order_by_id(o)); // :268
+    if (shuffle_groups(o, b->bmax)) hny_rust_sort::shuffle_level_groups(levels);
     if (cur_max > max_level) { // :272-276
       std::fill(in_new.begin(), in_new.end(), 0);
       max_level = cur_max;
@@ -855,8 +853,8 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     // 1-2 counted the surviving old records as "already inserted", so an update went in as one or two batches —
     // and new items that form a region of their own (a new topic appended to an index) searched a graph that
     // held none of them: measured recall 0.51 on such a region against 0.99 with the ramp
-    // (scripts/r3_new_region_update.py).  HNY_UPDATE_NO_RAMP=1: the old rule.
-    if (env_int("HNY_UPDATE_NO_RAMP", 0) != 0)
+    // (scripts/r3_new_region_update.py).  HNY_SCHED_UPDATE_NO_RAMP: the old rule.
+    if (o.schedule & HNY_SCHED_UPDATE_NO_RAMP)
       for (uint32_t s = 0; s < n; s++)
         if ((b->old_mask[s] & 1) && !b->deleted[s]) b->n_done0++;
     for (uint32_t s = 0; s < n; s++)

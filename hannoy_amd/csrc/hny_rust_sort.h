@@ -6,7 +6,7 @@
 // and with it the graph — is whatever this algorithm leaves behind.  With it, strict mode + batch_max = 1
 // rebuilds the reference's own 100-point snapshots record for record (tests: KAT-9); a stable sort (ids
 // ascending inside a level, what rounds 1-2 used and what Rust itself does for <= 20 pairs) gets 93 of their
-// 167 records wrong.  HNY_LEVEL_ORDER=id selects that older order.
+// 167 records wrong.  hny_build_opts.schedule & HNY_SCHED_LEVEL_ORDER_ID selects that older order.
 //
 // Only the steps that can reorder equal elements are spelled out: the existing-run check, the pivot choice
 // (median of 3, recursive from 64 elements), the branchless cyclic Lomuto partition, the quicksort driver

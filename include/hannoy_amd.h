@@ -99,7 +99,20 @@ typedef struct {
    * result is byte for byte the n_gpus == 1 result.  0 / 1 without `devices`: one GPU, no RCCL. */
   int32_t n_gpus;
   const int32_t *devices;
+  /* HNY_SCHED_* bits: the insertion schedules of rounds 1-2, kept for A/B comparisons.  They
+   * change which graph is built, so they are part of the options, not of the process environment.  0 = default. */
+  uint32_t schedule;
+  uint32_t reserved_;        /* 0 */
 } hny_build_opts;
+
+enum {
+  HNY_SCHED_NO_SHUFFLE = 1u,     /* batches are consecutive runs of the reference's order instead of a fixed
+                                  * pseudo-random sample of the level group */
+  HNY_SCHED_LEVEL_ORDER_ID = 2u, /* equal levels in ascending id order instead of the order Rust's
+                                  * sort_unstable_by leaves them in (hnsw.rs:268) */
+  HNY_SCHED_UPDATE_NO_RAMP = 4u  /* an update's first batch counts the surviving records as already inserted
+                                  * instead of ramping up from one member */
+};
 
 /* replaces: what FrozenReader hands to the builder (src/parallel.rs:33-45) */
 typedef struct {

@@ -1368,10 +1368,9 @@ int orc_build_incremental(const orc_opts *opts, const orc_items *items, const ui
 
   /* hnsw.rs:172-185; an update's batches ramp up from one member like a fresh build's (the product's rule,
    * DESIGN.md 1): counting the surviving old records as "already inserted" put a whole update into one batch,
-   * whose members cannot see each other.  ORC/HNY_UPDATE_NO_RAMP=1: that older rule. */
+   * whose members cannot see each other.  orc_opts.update_no_ramp: that older rule. */
   uint64_t n_done0 = 0;
-  if (const char *e = std::getenv("HNY_UPDATE_NO_RAMP"))
-    if (std::atoi(e) != 0)
+  if (opts->update_no_ramp)
       for (uint32_t s = 0; s < n; s++)
         if (B.has_disk[0][s] && !del[s]) n_done0++;
   int nthreads = std::max(1, opts->threads);

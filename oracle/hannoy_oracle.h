@@ -71,6 +71,9 @@ typedef struct {
   /* batch_max > 1: the items of a level group are taken in a fixed pseudo-random order (see
    * hannoy_oracle.cpp shuffle_level_groups); 1 = consecutive runs of the sorted order instead (rounds 1-2) */
   int32_t no_shuffle;
+  /* incremental builds: 1 = the first batch counts the surviving old records as "already inserted" (rounds 1-2)
+   * instead of ramping up from one member (the product's HNY_SCHED_UPDATE_NO_RAMP) */
+  int32_t update_no_ramp;
 } orc_opts;
 
 typedef struct {

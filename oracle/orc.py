@@ -38,7 +38,7 @@ class Opts(C.Structure):
     _fields_ = [("metric", C.c_int32), ("dim", C.c_uint32), ("M", C.c_uint32), ("M0", C.c_uint32),
                 ("ef_construction", C.c_uint32), ("alpha", C.c_float), ("order", C.c_int32),
                 ("threads", C.c_int32), ("batch_frac", C.c_double), ("batch_max", C.c_uint32),
-                ("level_sort", C.c_int32), ("no_shuffle", C.c_int32)]
+                ("level_sort", C.c_int32), ("no_shuffle", C.c_int32), ("update_no_ramp", C.c_int32)]
 
 
 class Items(C.Structure):
@@ -308,10 +308,15 @@ LEVEL_SORT_BY_ID, LEVEL_SORT_RUST = 0, 1  # orc_opts.level_sort (hnsw.rs:268)
 
 
 def make_opts(metric, dim, M=16, M0=32, ef=100, alpha=1.0, order=ORDER_X86, threads=1,
-              batch_frac=0.0, batch_max=0, level_sort=LEVEL_SORT_RUST, no_shuffle=None):
-    if no_shuffle is None:  # follows the product's knob, so that tests which set it compare like with like
-        no_shuffle = os.environ.get("HNY_NO_SHUFFLE", "0") not in ("", "0")
-    return Opts(metric, dim, M, M0, ef, alpha, order, threads, batch_frac, batch_max, level_sort, int(bool(no_shuffle)))
+              batch_frac=0.0, batch_max=0, level_sort=LEVEL_SORT_RUST, no_shuffle=False, update_no_ramp=False,
+              schedule=None):
+    """schedule: the product's hny_build_opts.schedule bits (HNY_SCHED_*), so that a test hands both sides the
+    same word: 1 = no_shuffle, 2 = level order by id, 4 = update_no_ramp"""
+    if schedule is not None:
+        no_shuffle, update_no_ramp = bool(schedule & 1), bool(schedule & 4)
+        level_sort = LEVEL_SORT_BY_ID if schedule & 2 else LEVEL_SORT_RUST
+    return Opts(metric, dim, M, M0, ef, alpha, order, threads, batch_frac, batch_max, level_sort,
+                int(bool(no_shuffle)), int(bool(update_no_ramp)))
 
 
 def gen_f32(seed32, skip, n):

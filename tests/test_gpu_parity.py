@@ -1288,7 +1288,8 @@ def test_ids_sorted_by_cluster_do_not_break_the_index(orc, hny, monkeypatch):
     a graph that does not contain its neighbourhood, and recall collapses (round 3 measured 0.42 instead of
     0.95 at C2).  The schedule therefore takes the items of a level group in a fixed pseudo-random order
     (hny_rust_sort.h shuffle_level_groups, restated in the oracle): recall on sorted ids equals recall on
-    shuffled ids, the graph equals the oracle's; HNY_NO_SHUFFLE=1 shows what it guards against."""
+    shuffled ids, the graph equals the oracle's; hny_build_opts.schedule = HNY_SCHED_NO_SHUFFLE shows what it guards
+    against."""
     rng = np.random.default_rng(8)
     n, dim, ncl, nq = 30000, 48, 30, 300
     cent = rng.uniform(-1, 1, (ncl, dim)).astype(np.float32)
@@ -1313,9 +1314,10 @@ def test_ids_sorted_by_cluster_do_not_break_the_index(orc, hny, monkeypatch):
     g, r_shuffled = recall()
     o = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, threads=8, batch_frac=1.0, batch_max=8192)
     _same_graph(g, o)
-    monkeypatch.setenv("HNY_NO_SHUFFLE", "1")
+    kw["schedule"] = hny.SCHED_NO_SHUFFLE
     g1, r_runs = recall()
-    o1 = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, threads=8, batch_frac=1.0, batch_max=8192)
+    o1 = orc.build(ds, M=16, M0=32, ef=64, order=orc.ORDER_WAVE, threads=8, batch_frac=1.0, batch_max=8192,
+                   schedule=hny.SCHED_NO_SHUFFLE)
     _same_graph(g1, o1)
     assert r_shuffled > 0.9, r_shuffled
     assert r_runs < r_shuffled - 0.1, (r_runs, r_shuffled)  # consecutive runs of sorted ids: a visibly worse index
@@ -1326,7 +1328,7 @@ def test_update_that_adds_a_new_region(orc, hny, monkeypatch):
     counted the surviving old records as "already inserted", so the 12 000 new items went in as one batch whose
     members cannot see each other: recall 0.51 on the new region.  An update's batches now ramp up from one
     member like a fresh build's: recall on the new region is what a fresh build of everything gives, and the
-    graph equals the oracle's under the same rule; HNY_UPDATE_NO_RAMP=1 shows what it guards against."""
+    graph equals the oracle's under the same rule; HNY_SCHED_UPDATE_NO_RAMP shows what it guards against."""
     rng = np.random.default_rng(5)
     dim, nA, nB, nq = 48, 30000, 12000, 300
     centA = rng.uniform(-1, 1, (30, dim)).astype(np.float32)
@@ -1360,9 +1362,8 @@ def test_update_that_adds_a_new_region(orc, hny, monkeypatch):
     assert g2.n_batches > 10
     r = recall(g2)
     assert r > 0.93, r
-    monkeypatch.setenv("HNY_UPDATE_NO_RAMP", "1")
-    g3 = hny.build_incremental(itAll, gA, ins, [], **kw)
-    _same_graph(g3, orc.build_incremental(dsAll, oA, ins, lvB, [], **kwo))
+    g3 = hny.build_incremental(itAll, gA, ins, [], schedule=hny.SCHED_UPDATE_NO_RAMP, **kw)
+    _same_graph(g3, orc.build_incremental(dsAll, oA, ins, lvB, [], schedule=hny.SCHED_UPDATE_NO_RAMP, **kwo))
     assert g3.n_batches <= 5 and recall(g3) < r - 0.2
 
 
