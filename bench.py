@@ -55,7 +55,12 @@ def parse():
                         "one warm-up + --alt-steps builds.  Default: overlap for the headline C2 workload, else none")
     p.add_argument("--alt-steps", type=int, default=1)
     p.add_argument("--cpu-full", action="store_true",
-                   help="time the CPU baseline on ALL vectors (about 80-100 s at C2) instead of a bounded sample")
+                   help="time the CPU baseline on ALL vectors whatever it takes (C4: ~4 minutes)")
+    p.add_argument("--cpu-sample-only", action="store_true",
+                   help="never time the full index on the CPU, even where it fits --cpu-full-budget")
+    p.add_argument("--cpu-full-budget", type=float, default=45.0,
+                   help="the CPU baseline is timed on ALL vectors when the calibration predicts at most this many "
+                        "seconds (C2: 22 s on 16 cores), else on a bounded sample of about --cpu-seconds")
     p.add_argument("--batch-frac", type=float, default=0.0)
     p.add_argument("--batch-max", type=int, default=0)
     p.add_argument("--queries", type=int, default=1000)
@@ -334,8 +339,13 @@ def main():
                 drv.run()
                 return b.finish()
 
-        for _ in range(warmup):
+        first_ms = None
+        for w_ in range(warmup):
+            tw = time.perf_counter()
             step()
+            if w_ == 0:  # the first build on a fresh builder: what a one-off hny_build pays beyond the upload
+                first_ms = round(1e3 * (time.perf_counter() - tw), 2)
+        timed_builds.first_build_ms = first_ms
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -401,6 +411,10 @@ def main():
                 r["reuse"] = round(alg / counted, 3)  # evaluated rows served by L2 instead of the fabric
             else:
                 r["wasted_traffic_ratio"] = round(counted / alg, 3)  # bytes moved beyond the rows
+            if pk.get("tcc_hit") is not None and pk.get("tcc_miss") is not None and pk["tcc_hit"] + pk["tcc_miss"] > 0:
+                # the same round's TCC_HIT_sum / TCC_MISS_sum pass over the k_walk dispatches: why algorithmic
+                # bytes can exceed what crossed the fabric
+                r["l2_hit_rate"] = round(pk["tcc_hit"] / (pk["tcc_hit"] + pk["tcc_miss"]), 4)
             r["traffic_read_bytes"] = int(pk["hbm_read_bytes_corrected_x2"] / max(1, pk["launches"]))
             r["traffic_write_bytes"] = int(pk["hbm_write_bytes"] / max(1, pk["launches"]))
             with open(os.path.join(ROOT, "hannoy_amd", "csrc", "hny_kernels.hip"), "rb") as f:
@@ -500,6 +514,7 @@ def main():
                    "batch_max": builder.opts.batch_max or H.default_batch_max(a.n),
                    "parallelism": f"item-sharded search x{a.gpus}, replicated graph",
                    "distance_order": "x86 (strict)" if a.x86_order else "wave"},
+        "first_build_ms": getattr(timed_builds, "first_build_ms", None),  # untimed warm-up 1: a fresh builder's first build
         "roofline": roof,
         "build": build_stats(graph),
         # who ran: ranks that really took part (dist.get_world_size() / replicas of the multi-builder),
@@ -556,15 +571,19 @@ def main():
                 cores = int(sw["best_threads"])
                 sweep_note = "profiles/r04_cpu_baseline_thread_sweep.json"
         ns = a.n if a.cpu_full else min(a.cpu_sample, a.n)
-        if ns <= 0:  # calibrate on 4000 items, then size the sample for ~cpu_seconds of wall time
+        if ns <= 0:  # calibrate on 4000 items, then: everything if that fits the budget, else a sample
             nc = min(4000, a.n)
             dsc = orc.Dataset(metric, a.dim, np.arange(nc, dtype=np.uint32), items.codes[:nc],
                               items.headers[:nc], draw_levels(nc, a.M, a.seed))
             t1 = time.perf_counter()
             orc.build(dsc, M=a.M, M0=M0, ef=a.ef, order=orc.ORDER_X86, threads=cores)
             rate = nc / max(time.perf_counter() - t1, 1e-3)
-            # the per-insert cost grows with the index: assume half the calibrated rate
-            ns = int(min(a.n, max(10000, 0.5 * rate * a.cpu_seconds)))
+            # the per-insert cost grows with the index: measured full-size rates are 0.3 - 0.5 of the
+            # 4000-item rate (C2: 22 s for 1M vectors where the calibration alone says 7 s)
+            if not a.cpu_sample_only and a.n / (0.3 * rate) <= a.cpu_full_budget:
+                ns = a.n
+            else:
+                ns = int(min(a.n, max(10000, 0.5 * rate * a.cpu_seconds)))
         lv = draw_levels(ns, a.M, a.seed)
         ds = orc.Dataset(metric, a.dim, np.arange(ns, dtype=np.uint32), items.codes[:ns],
                          items.headers[:ns], lv)
@@ -583,8 +602,28 @@ def main():
         # the committed full-size comparison of this workload, if there is one (scripts/r4_recall_parity.py: GPU-built vs
         # CPU-built index at the BASELINE size, same levels, same searcher, exact ground truth)
         short = cfg_name.split(" ")[0].lower()
+        f5 = os.path.join(ROOT, "profiles", f"r05_{short}_recall_sweep_{a.data}_cpu3.json")
+        if short in ("c2", "c3", "c4", "c5") and os.path.exists(f5) and not (a.batch_frac or a.batch_max or a.x86_order):
+            with open(f5) as f:
+                fj = json.load(f)
+            if fj.get("n") == a.n and fj.get("summary") and fj.get("cpu_builds"):
+                cb = fj["cpu_builds"]
+                gd = [g_ for g_ in fj["gpu_builds"] if g_.get("default")]
+                out["cpu_baseline"]["full_size_runs"] = {
+                    "cpu_builds": len(cb), "cores": cb[0]["threads"],
+                    "vectors_per_s": [c_["vec_per_s"] for c_ in cb], "seconds": [c_["build_s"] for c_ in cb],
+                    "queries": fj.get("queries"),
+                    "recall_at_10_by_ef_search": {
+                        e: {"cpu_median": v["cpu_median"], "cpu_min": v["cpu_min"], "cpu_max": v["cpu_max"],
+                            "gpu_default_schedule": next((g_["recall"] for g_ in v["gpu"]
+                                                          if gd and g_["batch_max"] == gd[0]["batch_max"]
+                                                          and g_["batch_frac"] == gd[0]["batch_frac"]), None)}
+                        for e, v in fj["summary"].items()},
+                    "source": f"profiles/{os.path.basename(f5)} (scripts/r5_recall_sweep.py --config {short.upper()} "
+                              f"--data {a.data} --cpu-builds {len(cb)}; exact f64 ground truth)"}
         fp = os.path.join(ROOT, "profiles", f"r04_{short}_recall_parity" + ("" if a.data == "overlap" else "_" + a.data) + ".json")
-        if short in ("c2", "c3", "c4", "c5") and os.path.exists(fp) and not (a.batch_frac or a.batch_max or a.x86_order):
+        if (short in ("c2", "c3") and os.path.exists(fp) and not os.path.exists(f5)
+                and not (a.batch_frac or a.batch_max or a.x86_order)):  # (r04's C4 files: ground truth broken at 10M)
             with open(fp) as f:
                 fj = json.load(f)
             if fj.get("n") == a.n and "recall_at_10" in fj:

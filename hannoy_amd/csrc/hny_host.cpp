@@ -286,9 +286,39 @@ struct hny_builder {
   DevBuf<u32> d_pool_retry, d_pool_ctr;
   DevBuf<u64> d_heap_c, d_heap_r;
   uint32_t heap_grid = 0, heap_c_cap = 0, heap_r_cap = 0, pool_ctr_used = 0;
+  u64 *heap_c_ptr = nullptr; // d_ops (borrowed while a batch is searched) or d_heap_c
+  // the four large arrays of the hny_graph this build will export, allocated and touched page by page on a helper
+  // thread WHILE the device builds (the host is idle then): finish() would otherwise pay the first touch of up to
+  // 1.3 GB of fresh pages (C4: 45 ms, C5: 25 ms of the step).  Owned by the builder until finish() hands them to
+  // the graph; hny_graph_free frees them plainly (rounds 3-4 kept them in a process-wide cache instead, which
+  // only helped the second build of a loop and held ~1.3 GB for the life of the process).
+  struct ExportBufs {
+    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+    std::thread th;
+    void join() {
+      if (th.joinable()) th.join();
+    }
+    void drop() {
+      join();
+      for (int i = 0; i < 4; i++) {
+        free(p[i]);
+        p[i] = nullptr;
+        cap[i] = 0;
+      }
+    }
+    ~ExportBufs() { drop(); }
+  } xbuf;
+  bool will_export = true;       // hny_multi.cpp: only rank 0 exports
+  uint64_t nrec_bound = 0, nbr_bound = 0;
   bool locality = true;
   u32 *h_l0 = nullptr, *h_up = nullptr, *h_cnt0 = nullptr, *h_cntu = nullptr; // pinned staging
-  DevBuf<u64> d_stats, d_stats_scratch, d_sel, d_cand, d_res_global, d_keys_a, d_keys_b, d_vals_a, d_vals_b;
+  DevBuf<u64> d_stats, d_stats_scratch, d_sel, d_cand, d_res_global;
+  // the link-op arrays of phase 2 (emit -> sort -> segments -> apply): four views of ONE allocation, because
+  // phase 1's safety net (k_walk_heap's `candidates` heaps) borrows the whole of it — the two phases of a batch
+  // never overlap on the builder's stream, and the heaps are the only large thing the retry path needs
+  DevBuf<u64> d_ops;
+  struct { u64 *p = nullptr; size_t n = 0; } d_keys_a, d_keys_b, d_vals_a, d_vals_b;
   DevBuf<unsigned char> d_sort_tmp;
   size_t sort_tmp_bytes = 0;
   uint32_t walk_slots = 0, bits_words = 0, log_cap = 0, rcap = 0, max_batch = 0;
@@ -886,6 +916,14 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   }
   if (b->entry_points.size() > HNY_MAX_EPS)
     return fail(HNY_ERR_UNSUPPORTED, "%zu entry points > %d", b->entry_points.size(), HNY_MAX_EPS);
+  for (uint32_t s = 0; s < n; s++) { // what finish() will export at most (its rec_mask)
+    if (b->deleted[s]) continue;
+    uint32_t m = b->old_mask[s];
+    if (b->ins_level[s] >= 0) m |= (2u << b->ins_level[s]) - 1u;
+    const uint32_t c = (uint32_t)__builtin_popcount(m);
+    b->nrec_bound += c;
+    b->nbr_bound += (m & 1u ? o.M0 : 0u) + (uint64_t)(c - (m & 1u)) * o.M;
+  }
 
   // ---- sizes ----
   b->top_layer_nodes = 0; // nodes a walk can meet on layer max_level: old records there + what gets inserted there
@@ -912,9 +950,11 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
                 "batch_max %u too large for M0 %u: %zu link ops per batch >= 2^%d (pass batch_max <= %u; the schedule "
                 "is part of the result, so it is never shrunk silently)",
                 b->bmax, o.M0, b->max_ops, HNY_SEQ_BITS, (uint32_t)((1ull << (HNY_SEQ_BITS - 1)) / std::max(o.M0, 2 * o.M) / 2));
-  // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (5 for binary codes <= 1 KB, see k_walk)
-  b->walk_slots = (uint32_t)std::min<int64_t>(
-      std::max(1, env_int("HNY_WALK_SLOTS", b->shape.nch == 1 && o.metric >= HNY_HAMMING ? 6144 : 4096)), 65536);
+  // resident walk waves: 256 CUs x 4 SIMDs x waves per SIMD (6 for binary codes <= 512 B on the register beam —
+  // the instances k_walk's launch bound gives six waves, see there; 4 otherwise)
+  const bool six_waves = b->shape.nch == 1 && b->shape.lpr <= 32 && o.metric >= HNY_HAMMING && b->rcap <= 128 &&
+                         env_int("HNY_NO_RB", 0) == 0;
+  b->walk_slots = (uint32_t)std::min<int64_t>(std::max(1, env_int("HNY_WALK_SLOTS", six_waves ? 6144 : 4096)), 65536);
   b->bits_words = (n + 31) / 32 + 1;
   b->log_cap = (uint32_t)std::max(1024, env_int("HNY_VISITED_LOG", 16384));
   b->vis_slots_env = env_int("HNY_VIS_SLOTS", -1);
@@ -989,10 +1029,12 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   }
   HIP_TRY(b->d_cand.alloc(cand_rows * b->rcap));
   HIP_TRY(b->d_cand_n.alloc(cand_rows));
-  HIP_TRY(b->d_keys_a.alloc(b->max_ops));
-  HIP_TRY(b->d_keys_b.alloc(b->max_ops));
-  HIP_TRY(b->d_vals_a.alloc(b->max_ops));
-  HIP_TRY(b->d_vals_b.alloc(b->max_ops));
+  HIP_TRY(b->d_ops.alloc(4 * b->max_ops));
+  b->d_keys_a.p = b->d_ops.p;
+  b->d_keys_b.p = b->d_ops.p + b->max_ops;
+  b->d_vals_a.p = b->d_ops.p + 2 * b->max_ops;
+  b->d_vals_b.p = b->d_ops.p + 3 * b->max_ops;
+  b->d_keys_a.n = b->d_keys_b.n = b->d_vals_a.n = b->d_vals_b.n = b->max_ops;
   HIP_TRY(b->d_seg_start.alloc(b->max_ops));
   HIP_TRY(b->d_nseg.alloc(4 + 16 + 8 * 16)); // + 8 per-XCD counters for each of the 16 work queues
   b->locality = env_int("HNY_NO_LOCALITY", 0) == 0;
@@ -1002,13 +1044,24 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   HIP_TRY(b->d_perm_b.alloc(cand_rows));
   HIP_TRY(b->d_eps0.alloc(cand_rows));
   {
-    // walk_layer on heaps (k_walk_heap): `candidates` never holds more than the items visited, `res` no more
-    // than a candidate row; as many blocks as ~1 GB of heaps allow
-    b->heap_c_cap = (uint32_t)std::min<uint64_t>((uint64_t)n + 1 + eps_cap_of(b.get()), (uint64_t)1 << 22);
+    // walk_layer on heaps (k_walk_heap): `candidates` never holds more than the items visited (+ the entry
+    // points), `res` no more than a candidate row.  The retry path normally sees no member, so the `candidates`
+    // heaps own no memory: they live in the link-op arrays (d_ops), idle while a batch is searched — rounds 3-4
+    // set ~1 GB per builder aside for them (x 8 replicas on a node) and clipped a heap at 2^22 entries, which a
+    // walk over > 4 M equidistant items would have overflowed.  Only a builder whose op arrays cannot hold ONE
+    // full heap (tiny batch_max on a large index) gets heaps of its own, of at most 2^25 entries (256 MB).
+    const uint64_t c_full = (uint64_t)n + 1 + eps_cap_of(b.get());
     b->heap_r_cap = b->rcap + 1;
-    const uint64_t per_block = ((uint64_t)b->heap_c_cap + b->heap_r_cap) * 8;
-    b->heap_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(slots, 512), ((uint64_t)1 << 30) / per_block));
-    HIP_TRY(b->d_heap_c.alloc((size_t)b->heap_grid * b->heap_c_cap));
+    if (b->d_ops.n >= c_full) {
+      b->heap_c_cap = (uint32_t)std::min<uint64_t>(c_full, 0xFFFFFFFFull);
+      b->heap_grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(slots, 512), b->d_ops.n / c_full);
+      b->heap_c_ptr = b->d_ops.p;
+    } else {
+      b->heap_c_cap = (uint32_t)std::min<uint64_t>(c_full, (uint64_t)1 << 25);
+      b->heap_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(slots, 512), ((uint64_t)1 << 25) / b->heap_c_cap));
+      HIP_TRY(b->d_heap_c.alloc((size_t)b->heap_grid * b->heap_c_cap));
+      b->heap_c_ptr = b->d_heap_c.p;
+    }
     HIP_TRY(b->d_heap_r.alloc((size_t)b->heap_grid * b->heap_r_cap));
     HIP_TRY(b->d_pool_retry.alloc(cand_rows));
     HIP_TRY(b->d_pool_ctr.alloc(2 * 64));
@@ -1140,12 +1193,14 @@ int hny_builder_reset(hny_builder *b) {
   return reset_graph(b);
 }
 
+static void start_export_prefault(hny_builder *b);
 int hny_builder_next_batch(hny_builder *b, hny_batch *out) {
   if (!b || !out) return fail(HNY_ERR_INVALID_ARG, "null argument");
   if (b->in_batch) return fail(HNY_ERR_INVALID_ARG, "previous batch not applied");
   if (b->finalized && b->pos < b->order.size()) return fail(HNY_ERR_INVALID_ARG, "graph already finalised");
   memset(out, 0, sizeof *out);
   if (b->pos >= b->order.size()) return HNY_OK;
+  if (b->pos == 0) start_export_prefault(b);
   size_t gend = group_end(b, b->pos);
   uint32_t L = b->order_level[b->pos];
   uint64_t bs = hny_batch_size(b->frac, b->bmax, b->n_done);
@@ -1269,7 +1324,7 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     WalkArgs h = w;
     h.queue = pc + 1;
     h.xcd_tile = 0;
-    h.heap_c = b->d_heap_c.p;
+    h.heap_c = b->heap_c_ptr;
     h.heap_r = b->d_heap_r.p;
     h.heap_c_cap = b->heap_c_cap;
     h.heap_r_cap = b->heap_r_cap;
@@ -1520,54 +1575,48 @@ static int device_error_words(hny_builder *b, const u64 *stats) {
   return HNY_OK;
 }
 
-// The four large arrays of a hny_graph (C4: 1.3 GB together) come from a one-deep cache of what hny_graph_free
-// last released: a caller that rebuilds in a loop — drops the previous graph, builds the next — otherwise pays
-// the first touch of fresh pages again on every export (glibc hands blocks of this size back to the kernel on
-// free): 25 ms of a 550-ms C5 step, 45 ms at C4.  Capacities come from malloc_usable_size; a cached block is
-// only taken when it is not more than twice what is asked for.
-namespace {
-struct GraphBufCache {
-  std::mutex mu;
-  void *p[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t cap[4] = {0, 0, 0, 0};
-  ~GraphBufCache() {
-    for (void *q : p) free(q);
-  }
-} g_gbuf;
-void *gbuf_alloc(int slot, size_t bytes) {
-  {
-    std::lock_guard<std::mutex> lk(g_gbuf.mu);
-    if (g_gbuf.p[slot] && g_gbuf.cap[slot] >= bytes && g_gbuf.cap[slot] / 2 <= bytes + (1u << 20)) {
-      void *q = g_gbuf.p[slot];
-      g_gbuf.p[slot] = nullptr;
-      g_gbuf.cap[slot] = 0;
-      return q;
+// Prepare the export arrays of the build that is starting (hny_builder.xbuf): sizes are upper bounds known when
+// the builder is created (which records exist never changes; a list holds at most its cap), finish() trims the
+// neighbour array to what the lists really hold.
+static void start_export_prefault(hny_builder *b) {
+  if (!b->will_export) return;
+  b->xbuf.join();
+  const size_t want[4] = {(size_t)std::max<uint64_t>(b->nrec_bound, 1) * 4, (size_t)std::max<uint64_t>(b->nrec_bound, 1),
+                          (size_t)(b->nrec_bound + 1) * 8, (size_t)std::max<uint64_t>(b->nbr_bound, 1) * 4};
+  if (want[0] + want[1] + want[2] + want[3] < ((size_t)8 << 20)) return; // small: finish() allocates
+  bool have = true;
+  for (int i = 0; i < 4; i++) have = have && b->xbuf.p[i] && b->xbuf.cap[i] >= want[i];
+  if (have) return; // a build that was reset before its finish(): the arrays are still here, and touched
+  auto *x = &b->xbuf;
+  x->th = std::thread([x, want]() {
+    for (int i = 0; i < 4; i++) {
+      if (x->p[i] && x->cap[i] >= want[i]) continue;
+      free(x->p[i]);
+      x->p[i] = malloc(want[i]);
+      x->cap[i] = x->p[i] ? want[i] : 0;
+      volatile unsigned char *q = (volatile unsigned char *)x->p[i];
+      for (size_t o = 0; q && o < want[i]; o += 4096) q[o] = 0;
     }
+  });
+}
+// one export array: the prepared one when it is large enough, else a fresh allocation
+static void *take_export_buf(hny_builder *b, int slot, size_t bytes) {
+  b->xbuf.join();
+  if (b->xbuf.p[slot] && b->xbuf.cap[slot] >= bytes) {
+    void *q = b->xbuf.p[slot];
+    b->xbuf.p[slot] = nullptr;
+    b->xbuf.cap[slot] = 0;
+    return q;
   }
   return malloc(bytes);
 }
-void gbuf_release(int slot, void *q) {
-  if (!q) return;
-  const size_t cap = malloc_usable_size(q);
-  void *drop = q;
-  if (cap >= ((size_t)1 << 20)) {
-    std::lock_guard<std::mutex> lk(g_gbuf.mu);
-    if (cap > g_gbuf.cap[slot]) {
-      drop = g_gbuf.p[slot];
-      g_gbuf.p[slot] = q;
-      g_gbuf.cap[slot] = cap;
-    }
-  }
-  free(drop);
-}
-} // namespace
 
 void hny_graph_free(hny_graph *g) {
   if (!g) return;
-  gbuf_release(0, (void *)g->rec_item);
-  gbuf_release(1, (void *)g->rec_layer);
-  gbuf_release(2, (void *)g->rec_offset);
-  gbuf_release(3, (void *)g->neighbours);
+  free((void *)g->rec_item);
+  free((void *)g->rec_layer);
+  free((void *)g->rec_offset);
+  free((void *)g->neighbours);
   free((void *)g->entry_points);
   free(g);
 }
@@ -1648,13 +1697,13 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
   // the graph owns its arrays from the start, so that every error return below frees them
   std::unique_ptr<hny_graph, void (*)(hny_graph *)> gh((hny_graph *)calloc(1, sizeof(hny_graph)), hny_graph_free);
   hny_graph *g = gh.get();
-  uint32_t *rec_item = (uint32_t *)gbuf_alloc(0, std::max<uint64_t>(nrec, 1) * 4);
-  uint8_t *rec_layer = (uint8_t *)gbuf_alloc(1, std::max<uint64_t>(nrec, 1));
-  uint64_t *rec_off = (uint64_t *)gbuf_alloc(2, (nrec + 1) * 8);
+  uint32_t *rec_item = (uint32_t *)take_export_buf(b, 0, std::max<uint64_t>(nrec, 1) * 4);
+  uint8_t *rec_layer = (uint8_t *)take_export_buf(b, 1, std::max<uint64_t>(nrec, 1));
+  uint64_t *rec_off = (uint64_t *)take_export_buf(b, 2, (nrec + 1) * 8);
   if (!g || !rec_item || !rec_layer || !rec_off) {
-    gbuf_release(0, rec_item);
-    gbuf_release(1, rec_layer);
-    gbuf_release(2, rec_off);
+    free(rec_item);
+    free(rec_layer);
+    free(rec_off);
     return fail(HNY_ERR_OOM, "out of host memory for %llu records", (unsigned long long)nrec);
   }
   g->rec_item = rec_item;
@@ -1691,7 +1740,7 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
         }
     }
   });
-  uint32_t *nbrs = (uint32_t *)gbuf_alloc(3, std::max<uint64_t>(rec_off[nrec], 1) * 4);
+  uint32_t *nbrs = (uint32_t *)take_export_buf(b, 3, std::max<uint64_t>(rec_off[nrec], 1) * 4);
   if (!nbrs) return fail(HNY_ERR_OOM, "out of host memory for %llu links", (unsigned long long)rec_off[nrec]);
   g->neighbours = nbrs;
   HIP_TRY(hipStreamSynchronize(b->stream)); // the lists have arrived
@@ -1713,6 +1762,8 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
       }
     }
   });
+  // the prepared array was sized for full lists: hand the unused tail back (in place for blocks of this size)
+  if (void *shrunk = realloc(nbrs, std::max<uint64_t>(rec_off[nrec], 1) * 4)) g->neighbours = nbrs = (uint32_t *)shrunk;
   uint32_t *eps = (uint32_t *)malloc(std::max<size_t>(b->entry_points.size(), 1) * 4);
   for (size_t i = 0; i < b->entry_points.size(); i++) eps[i] = b->ids[b->entry_points[i]];
   g->n_records = nrec;
@@ -1852,6 +1903,7 @@ int hny_builder_load(const hny_build_opts *opts, const hny_items *items, const h
 // hny_multi.cpp: the distance-evaluation counters of a replica.  Work that every rank repeats (ramp-up
 // batches, small deferred sets, fill_gaps) is counted on rank 0 only: the other ranks point their kernels'
 // counter block at a scratch copy meanwhile (the error words in it are the same on every replica).
+extern "C" void hny_internal_builder_set_export(hny_builder *b, int on) { b->will_export = on != 0; }
 extern "C" int hny_internal_builder_count_evals(hny_builder *b, int on) {
   if (!b) return fail(HNY_ERR_INVALID_ARG, "null builder");
   HIP_TRY(hipSetDevice(b->device));
@@ -2165,7 +2217,7 @@ static int search_knn_impl(hny_builder *b, uint64_t nq, const void *qvectors, si
       h.pool_retry = dlist.p + 2;
       h.n_pool_retry = dlist.p;
       h.queue = dlist.p + 1;
-      h.heap_c = b->d_heap_c.p;
+      h.heap_c = b->heap_c_ptr;
       h.heap_c_cap = b->heap_c_cap;
       h.heap_r = dheap_r.p;
       h.heap_r_cap = rcap + 1;

@@ -1756,13 +1756,15 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
 // binary codes of at most 1 KB (NCH == 1): the specialised BUILD kernels run 6 waves per SIMD in 79 VGPRs (two
 // spilled) — the walk on 128-B codes is bound by instruction issue and latency, and with the visited set in LDS
 // the sixth wave pays (C5 walk 0.401 -> 0.377 s with 6 144 resident waves and 448 buckets; 7 waves: 0.382, 9
-// spilled VGPRs and too little LDS left for the table).  The Reader's variant carries the exhaustive fallback
+// spilled VGPRs and too little LDS left for the table).  Only walk_layer_short was shown to fit (codes of at
+// most 512 B, register beam): codes of 513 - 1 024 B and the LDS-beam variant (ef >= 128) run walk_one_layer,
+// measured at ~96 VGPRs, and keep 4 waves.  The Reader's variant carries the exhaustive fallback
 // and spills at 96: 4 waves; the f32 kernels of that row size need 128 VGPRs; the general kernels spill at 4.
 #ifndef HNY_WALK_WPE_SMALL
 #define HNY_WALK_WPE_SMALL 6
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, int RC = 0>
-__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <= 32 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
   constexpr bool RB = RC != 0;
   constexpr int RCN = RC ? RC : 1;
   static_assert(!(RB && (BIG_EPS || SP == 0)), "register beam: specialised kernels only");

@@ -220,6 +220,7 @@ struct Job {
 };
 
 extern "C" int hny_internal_builder_count_evals(hny_builder *b, int on);
+extern "C" void hny_internal_builder_set_export(hny_builder *b, int on); // only the exporting rank prepares arrays
 extern "C" int hny_internal_builder_read_evals(hny_builder *b, uint64_t out3[3]);
 
 } // namespace
@@ -280,6 +281,7 @@ int run_rank(hny_multi_builder &mb, int rank, hny_graph **out, uint64_t *checksu
   int rc = hipSetDevice(device) == hipSuccess ? HNY_OK : failf(HNY_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
   if (!rc && mb.ran) rc = hny_builder_reset(b); // a second run: empty graph again, vectors stay in HBM
   if (!rc) rc = hny_internal_builder_count_evals(b, 1);
+  if (!rc) hny_internal_builder_set_export(b, rank == 0 || env_int("HNY_MGPU_VERIFY", 0) != 0);
   if (!rc) rc = hny_builder_set_profiling(b, mb.profiling ? 1 : 0);
   rc = sh.agree(rank, rc);
   if (rc) return rc;

@@ -31,6 +31,9 @@ def load(path, counter):
 
 def main():
     f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    # optional 4th argument: a TCC_HIT_sum / TCC_MISS_sum pass of the same workload (L2 hit rate per kernel family)
+    hit = load(sys.argv[4], "TCC_HIT_sum") if len(sys.argv) > 4 else {}
+    miss = load(sys.argv[4], "TCC_MISS_sum") if len(sys.argv) > 4 else {}
     out = {}
     for k in sorted(set(f) | set(w)):
         n = max(f[k][0], w[k][0])
@@ -39,6 +42,9 @@ def main():
         out[k] = {"launches": n, "fetch_size_kib": f[k][1], "write_size_kib": w[k][1],
                   "hbm_read_bytes_corrected_x2": rd, "hbm_write_bytes": wr,
                   "hbm_bytes_per_launch": (rd + wr) / max(n, 1)}
+        if k in hit or k in miss:
+            h, m = hit[k][1] if k in hit else 0.0, miss[k][1] if k in miss else 0.0
+            out[k].update({"tcc_hit": h, "tcc_miss": m, "l2_hit_rate": h / max(h + m, 1.0)})
     import hashlib, os
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hannoy_amd", "csrc", "hny_kernels.hip")
     meta = dict(out)
@@ -46,7 +52,8 @@ def main():
     json.dump(meta, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         print(f"{k:12s} launches {v['launches']:5d}  read {v['hbm_read_bytes_corrected_x2'] / 1e9:9.1f} GB"
-              f"  write {v['hbm_write_bytes'] / 1e9:8.1f} GB")
+              f"  write {v['hbm_write_bytes'] / 1e9:8.1f} GB" +
+              (f"  L2 hit rate {v['l2_hit_rate']:.3f}" if "l2_hit_rate" in v else ""))
 
 
 if __name__ == "__main__":
