@@ -730,8 +730,6 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
   // builds: k_fill_gaps_wg), strict mode's one-wave kernels (k_prune, k_apply) take them 64 slots at a time —
   // for fresh builds and loaded graphs; a strict-mode UPDATE of such lists (k_fill_gaps: one lane per slot) is refused
   const bool bigcap = o.M0 > HNY_MAX_CAP;
-  if (bigcap && o.x86_order && inc && !inc->load_only)
-    return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: incremental builds in the wave order only (no x86_order)", o.M0, HNY_MAX_CAP);
   if (o.ef_construction == 0 || o.ef_construction > HNY_MAX_EF)
     return fail(HNY_ERR_UNSUPPORTED, "ef_construction %u outside [1, %d]", o.ef_construction,
                 HNY_MAX_EF);
@@ -967,8 +965,9 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
     // the workgroup prune kernels carry their own wave-order arithmetic: strict mode and very long
     // rows use the single-wave kernels, which all go through dist_rows
     b->wave_prune_only = b->shape.nch > 8 || o.x86_order; // the one-wave prune: strict mode, rows beyond 8 KB
-    if (bigcap && b->wave_prune_only && inc && !inc->load_only)
-      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: an incremental build needs the workgroup kernels (rows <= 8 KB, wave order)",
+    // (strict mode updates of lists beyond 64 slots: k_fill_gaps_wg with the one-wave prune inside, round 5)
+    if (bigcap && b->shape.nch > 8 && inc && !inc->load_only)
+      return fail(HNY_ERR_UNSUPPORTED, "M0 %u > %d: an incremental build needs the workgroup kernels (rows <= 8 KB)",
                   o.M0, HNY_MAX_CAP);
   }
 

@@ -4288,7 +4288,19 @@ __global__ __launch_bounds__(256) void k_fill_gaps_wg(GraphDev g, const u64 *rec
       sorted[rk] = mine;
     }
     __syncthreads();
-    const int s_len = wg_prune<LPR, NCH, 4>(g, sorted, n, (int)cap, L, evals);
+    int s_len;
+    if (g.x86_order) {
+      // strict mode: wg_prune carries its own wave-order arithmetic, so wave 0 runs the one-wave prune (dist_rows ->
+      // the reference's x86 summation order, lists taken 64 slots at a time) on the workgroup's arrays
+      if (w == 0) {
+        const int sl = wave_prune<LPR, NCH>(g, sorted, n, (int)cap, L.S, L.s_ids, wsd, evals);
+        if (ln == 0) misc[6] = sl;
+      }
+      __syncthreads();
+      s_len = misc[6];
+    } else {
+      s_len = wg_prune<LPR, NCH, 4>(g, sorted, n, (int)cap, L, evals);
+    }
     __syncthreads();
     for (u32 e = (u32)tid; e < cap; e += 256u) {
       const bool on = (int)e < s_len;

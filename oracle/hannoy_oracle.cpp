@@ -257,7 +257,7 @@ inline uint32_t wave_nch(uint32_t dim4, uint32_t lpr) {
  * runs ONE fma chain over its 4*NCH elements in index order; the LPR partials are then combined
  * with an xor butterfly, offsets LPR/2 ... 1.  (hannoy_amd/csrc/hny_kernels.hip: row_partial,
  * butterfly_f32) */
-float wave_reduce(int op, const void *a, const void *b, uint32_t dim) {
+float wave_reduce_scalar(int op, const void *a, const void *b, uint32_t dim) {
   uint32_t dim4 = (dim + 3) / 4, lpr = wave_lpr(dim);
   uint32_t nch = wave_nch(dim4, lpr);
   float v[64];
@@ -288,6 +288,80 @@ float wave_reduce(int op, const void *a, const void *b, uint32_t dim) {
   }
   return v[0];
 }
+
+#if defined(__AVX2__) && defined(__FMA__)
+/* The same arithmetic, eight lanes of the group per AVX register (round 5: the full-size parity runs — 10M x 128 —
+ * spend their time here).  A block of 8 lanes t0..t0+7 and chunk c own 32 consecutive floats; an 8 x 4 transpose
+ * turns them into J0..J3 (element j of every lane), in lane order (t0 t2 t4 t6 | t1 t3 t5 t7) for all four alike,
+ * so each lane's fma chain runs in index order exactly as in wave_reduce_scalar.  Butterfly: offsets >= 8 pair
+ * whole blocks; 4, 2, 1 are position swaps i^2, i^1 inside the 128-bit halves and the swap of the halves in that
+ * lane order.  a + b == b + a, so every lane ends with the same bits: lane 0 is returned.
+ * tests/test_oracle_kat.py checks it against the scalar form bit for bit over dims 1..4096. */
+static inline void transpose_8x4(__m256 r0, __m256 r1, __m256 r2, __m256 r3, __m256 (&J)[4]) {
+  __m256 a = _mm256_unpacklo_ps(r0, r1), b = _mm256_unpacklo_ps(r2, r3);
+  __m256 c = _mm256_unpackhi_ps(r0, r1), d = _mm256_unpackhi_ps(r2, r3);
+  J[0] = _mm256_castpd_ps(_mm256_unpacklo_pd(_mm256_castps_pd(a), _mm256_castps_pd(b)));
+  J[1] = _mm256_castpd_ps(_mm256_unpackhi_pd(_mm256_castps_pd(a), _mm256_castps_pd(b)));
+  J[2] = _mm256_castpd_ps(_mm256_unpacklo_pd(_mm256_castps_pd(c), _mm256_castps_pd(d)));
+  J[3] = _mm256_castpd_ps(_mm256_unpackhi_pd(_mm256_castps_pd(c), _mm256_castps_pd(d)));
+}
+template <int OP>
+static float wave_reduce_avx(const float *a, const float *b, uint32_t lpr, uint32_t nch) {
+  const uint32_t nb = lpr / 8;
+  __m256 acc[8];
+  const __m256 sign = _mm256_set1_ps(-0.0f);
+  for (uint32_t k = 0; k < nb; k++) {
+    __m256 s = _mm256_setzero_ps();
+    for (uint32_t c = 0; c < nch; c++) {
+      const float *pa = a + 4 * ((size_t)c * lpr + 8 * k), *pb = b + 4 * ((size_t)c * lpr + 8 * k);
+      __m256 X[4], Y[4];
+      transpose_8x4(_mm256_loadu_ps(pa), _mm256_loadu_ps(pa + 8), _mm256_loadu_ps(pa + 16), _mm256_loadu_ps(pa + 24), X);
+      transpose_8x4(_mm256_loadu_ps(pb), _mm256_loadu_ps(pb + 8), _mm256_loadu_ps(pb + 16), _mm256_loadu_ps(pb + 24), Y);
+      for (int j = 0; j < 4; j++) {
+        if (OP == WOP_DOT) {
+          s = _mm256_fmadd_ps(X[j], Y[j], s);
+        } else if (OP == WOP_EUCLID) {
+          __m256 d = _mm256_sub_ps(X[j], Y[j]);
+          s = _mm256_fmadd_ps(d, d, s);
+        } else {
+          s = _mm256_add_ps(s, _mm256_andnot_ps(sign, _mm256_sub_ps(X[j], Y[j])));
+        }
+      }
+    }
+    acc[k] = s;
+  }
+  for (uint32_t off = nb / 2; off >= 1; off >>= 1) { /* lane offsets lpr/2 .. 8 */
+    __m256 w[8];
+    for (uint32_t k = 0; k < nb; k++) w[k] = _mm256_add_ps(acc[k], acc[k ^ off]);
+    for (uint32_t k = 0; k < nb; k++) acc[k] = w[k];
+  }
+  __m256 v = acc[0];
+  v = _mm256_add_ps(v, _mm256_permute_ps(v, 0x4E));        /* offset 4 */
+  v = _mm256_add_ps(v, _mm256_permute_ps(v, 0xB1));        /* offset 2 */
+  v = _mm256_add_ps(v, _mm256_permute2f128_ps(v, v, 1));   /* offset 1 */
+  return _mm256_cvtss_f32(v);
+}
+float wave_reduce(int op, const void *a, const void *b, uint32_t dim) {
+  const uint32_t dim4 = (dim + 3) / 4, lpr = wave_lpr(dim), nch = wave_nch(dim4, lpr);
+  const size_t padded = (size_t)4 * lpr * nch;
+  const float *fa = (const float *)a, *fb = (const float *)b;
+  float ta[4096], tb[4096];
+  if (padded > 4096) return wave_reduce_scalar(op, a, b, dim);
+  if (padded != dim) { /* the zero padding the kernel's lanes see beyond the row */
+    memcpy(ta, a, (size_t)dim * 4);
+    memcpy(tb, b, (size_t)dim * 4);
+    memset(ta + dim, 0, (padded - dim) * 4);
+    memset(tb + dim, 0, (padded - dim) * 4);
+    fa = ta;
+    fb = tb;
+  }
+  if (op == WOP_DOT) return wave_reduce_avx<WOP_DOT>(fa, fb, lpr, nch);
+  if (op == WOP_EUCLID) return wave_reduce_avx<WOP_EUCLID>(fa, fb, lpr, nch);
+  return wave_reduce_avx<WOP_MANHATTAN>(fa, fb, lpr, nch);
+}
+#else
+float wave_reduce(int op, const void *a, const void *b, uint32_t dim) { return wave_reduce_scalar(op, a, b, dim); }
+#endif
 
 /* ------------------------------------------------------------------ */
 /* codecs                                                              */
@@ -441,8 +515,11 @@ struct Builder {
 };
 
 struct Scratch {
-  std::vector<uint32_t> stamp;
-  uint32_t epoch = 0;
+  /* RoaringBitmap of one walk: a bitset over the slots + the words it touched (cleared by that list).  Rounds 1-4
+   * kept one u32 epoch stamp per slot: 40 MB per thread at 10M items, a cache miss per neighbour looked at; the
+   * bitset of the same index is 1.25 MB. */
+  std::vector<uint64_t> bits;
+  std::vector<uint32_t> touched;
   uint64_t evals = 0;
   uint64_t evals_walk = 0; /* the hnsw.rs:476,503 call sites alone (schedule-determined) */
   std::vector<uint32_t> nbuf;
@@ -452,19 +529,26 @@ struct Scratch {
   bool tracing = false;
   uint32_t trace_q = 0;
   void begin(uint32_t n) {
-    if (stamp.size() != n) {
-      stamp.assign(n, 0);
-      epoch = 0;
+    const size_t w = ((size_t)n + 63) / 64;
+    if (bits.size() != w) {
+      bits.assign(w, 0);
+      touched.clear();
     }
-    if (++epoch == 0) {
-      std::fill(stamp.begin(), stamp.end(), 0);
-      epoch = 1;
+    if (touched.size() > w / 8) {
+      std::fill(bits.begin(), bits.end(), 0);
+    } else {
+      for (uint32_t t : touched) bits[t] = 0;
     }
+    touched.clear();
   }
+  bool seen(uint32_t s) const { return (bits[s >> 6] >> (s & 63)) & 1u; }
   /* RoaringBitmap::insert → true if newly inserted */
   bool visit(uint32_t s) {
-    if (stamp[s] == epoch) return false;
-    stamp[s] = epoch;
+    uint64_t &w = bits[s >> 6];
+    const uint64_t m = 1ull << (s & 63);
+    if (w & m) return false;
+    if (!w) touched.push_back(s >> 6);
+    w |= m;
     return true;
   }
 };
@@ -523,6 +607,17 @@ void walk_layer(Builder &B, Scratch &S, const QDist &qd, const std::vector<uint3
       for (const Link &l : nl->links) S.nbuf.push_back(l.id);
       B.unlock(nl);
     }
+    /* (hints only, no semantics: at 10M items every stamp, row and header below is a cache miss; issuing them
+     * together overlaps the misses the loop would otherwise take one at a time) */
+    for (uint32_t p : S.nbuf) __builtin_prefetch(&S.bits[p >> 6]);
+    for (uint32_t p : S.nbuf)
+      if (!S.seen(p)) {
+        const uint8_t *v = B.vec(p);
+        for (size_t o = 0; o < B.dist.vbytes; o += 64) __builtin_prefetch(v + o);
+        __builtin_prefetch(B.hdr(p));
+      }
+    if (!cand.empty())
+      if (NodeList *nx = B.list(layer, cand.top().id)) __builtin_prefetch(nx);
     for (uint32_t p : S.nbuf) {
       if (!S.visit(p)) continue; /* :493 */
       if (B.incremental && !B.has_vec[p]) continue; /* MissingKey => deleted item, :498-502 */
@@ -549,8 +644,14 @@ void robust_prune(Builder &B, std::vector<Link> cands, uint32_t cap, uint64_t &e
   std::sort(cands.begin(), cands.end(),
             [](const Link &a, const Link &b) { return link_key(a) < link_key(b); });
   selected.clear();
-  for (const Link &c : cands) { /* pop from the back of the descending sort = ascending */
+  for (size_t ci = 0; ci < cands.size(); ci++) { /* pop from the back of the descending sort = ascending */
+    const Link &c = cands[ci];
     if (selected.size() == cap) break;
+    if (ci + 2 < cands.size()) { /* hint: the row two candidates ahead */
+      const uint8_t *v = B.vec(cands[ci + 2].id);
+      for (size_t o = 0; o < B.dist.vbytes; o += 64) __builtin_prefetch(v + o);
+      __builtin_prefetch(B.hdr(cands[ci + 2].id));
+    }
     bool ok = true;
     for (const Link &i : selected) {
       float d = B.d_items(c.id, i.id, evals);
@@ -560,8 +661,9 @@ void robust_prune(Builder &B, std::vector<Link> cands, uint32_t cap, uint64_t &e
         break;
       }
     }
+    static const bool link_stats = std::getenv("ORC_PRUNE_LINK_STATS") != nullptr; /* (not per rejection: getenv scans environ) */
     if (ok) selected.push_back(c);
-    else if (std::getenv("ORC_PRUNE_LINK_STATS")) {
+    else if (link_stats) {
       /* diagnostics (scripts/r3_prune_links.py): could the rejection have been read off STORED links — a
        * selected s that violates and has c in its layer-0 list (with its distance), or sits in c's list? */
       static std::atomic<uint64_t> n_rej{0}, via_s{0}, via_c{0}, via_any{0}, n_seen{0};
@@ -722,6 +824,11 @@ float orc_distance(int32_t metric, int32_t order, uint32_t dim, const void *pv, 
   Dist d{metric, order, dim, vec_bytes(metric, dim)};
   return d(pv, ph, qv, qh);
 }
+// the wave-order reduction both ways: [0] the AVX2 form the builds use, [1] the scalar statement of the order
+void orc_wave_reduce_both(int32_t op, uint32_t dim, const float *a, const float *b, float out[2]) {
+  out[0] = wave_reduce(op, a, b, dim);
+  out[1] = wave_reduce_scalar(op, a, b, dim);
+}
 // the same for many pairs of stored items (test helper: >= 1M-pair distance parity)
 void orc_distance_pairs(int32_t metric, int32_t order, uint32_t dim, const void *codes, size_t code_stride,
                         const void *headers, size_t header_stride, uint64_t n_pairs, const uint32_t *a,
@@ -872,8 +979,42 @@ static void run_schedule(Builder &B, const orc_opts *opts,
       bool was_threaded = B.threaded;
       B.threaded = false; /* apply is sequential by definition */
       for (size_t i = 0; i < cnt; i++) register_item(B, ord[pos + i].first, ord[pos + i].second);
-      for (size_t i = 0; i < cnt; i++)
-        insert_apply(B, ord[pos + i].first, ord[pos + i].second, sels[i], evals, links);
+      if (nthreads == 1 || cnt < 256) {
+        for (size_t i = 0; i < cnt; i++)
+          insert_apply(B, ord[pos + i].first, ord[pos + i].second, sels[i], evals, links);
+      } else {
+        /* The same sequence of add_link calls, executed by several threads without changing its outcome: an
+         * add_link touches only the lists of its TARGET, so calls on different targets commute; every thread
+         * walks the whole sequence in batch order and performs the calls whose target it owns (blocks of 16
+         * slots, round robin) — per target the order is the sequential one, no list is shared, no lock taken.
+         * (Round 5: at 10M items this phase, on one thread, was most of the oracle's build time.) */
+        const uint32_t T = (uint32_t)nthreads;
+        std::vector<uint64_t> tev(T, 0), tln(T, 0);
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < T; t++)
+          th.emplace_back([&, t]() {
+            uint64_t ev = 0, ln = 0;
+            for (size_t i = 0; i < cnt; i++) {
+              const uint32_t q = ord[pos + i].first, lvl = ord[pos + i].second;
+              const bool mine_q = (q >> 4) % T == t;
+              for (int32_t l = (int32_t)lvl; l >= 0; l--)
+                for (const Link &sl : sels[i].per_layer[l]) {
+                  if (mine_q) {
+                    add_link(B, q, sl, (uint32_t)l, ev);
+                    ln += 2; /* build_stats.incr_link_count(2) :323, counted by the owner of q */
+                  }
+                  if ((sl.id >> 4) % T == t) add_link(B, sl.id, Link{sl.d, q}, (uint32_t)l, ev);
+                }
+            }
+            tev[t] = ev;
+            tln[t] = ln;
+          });
+        for (auto &x : th) x.join();
+        for (uint32_t t = 0; t < T; t++) {
+          evals += tev[t];
+          links += tln[t];
+        }
+      }
       B.threaded = was_threaded;
       n_done += cnt;
       pos = bend;
@@ -1683,7 +1824,7 @@ int orc_search_ex(int32_t metric, int32_t order, uint32_t dim, const orc_items *
     std::vector<Link> neighbours = res;
     if (neighbours.size() < k) { /* exhaustive fallback :771-795 / :864-890 */
       for (uint32_t s = 0; s < n; s++) {
-        if (path.stamp[s] == path.epoch) continue;
+        if (path.seen(s)) continue;
         size_t ef2;
         if (by_item) ef2 = k - neighbours.size(); /* :878 */
         else ef2 = ef_search > neighbours.size() ? ef_search - neighbours.size() : 0; /* :783 */

@@ -103,6 +103,9 @@ float orc_distance(int32_t metric, int32_t order, uint32_t dim, const void *pv, 
 void orc_distance_pairs(int32_t metric, int32_t order, uint32_t dim, const void *codes, size_t code_stride,
                         const void *headers, size_t header_stride, uint64_t n_pairs, const uint32_t *a,
                         const uint32_t *b, float *out, int32_t threads);
+/* the WAVE-order reduction (op 0 dot, 1 squared L2, 2 L1) computed by the AVX2 form the builds use ([0]) and by the
+ * scalar statement of the order ([1]): the two must agree bit for bit (tests/test_oracle_kat.py) */
+void orc_wave_reduce_both(int32_t op, uint32_t dim, const float *a, const float *b, float out[2]);
 float orc_dot(int32_t order, uint32_t dim, const float *a, const float *b);
 float orc_sqeuclid(int32_t order, uint32_t dim, const float *a, const float *b);
 /* scalar emulation of the AVX/SSE kernels (always available), for self-checks

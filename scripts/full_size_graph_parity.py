@@ -3,11 +3,15 @@
 
 The regular -m gpu suite checks the full-size builds through size-independent properties (the oracle
 needs minutes per config on the box's host cores); this script does the whole comparison once per
-round and writes gpurun_out/r04_full_size_graph_parity.json (-> profiles/):  same data as bench.py, same levels, same
+round and writes gpurun_out/r05_full_size_graph_parity.json (-> profiles/):  same data as bench.py, same levels, same
 batch schedule, oracle in the wave summation order on every host core -> identical records
 (rec_item, rec_layer, offsets, neighbours), entry points, link count and walk-evaluation count.
 
-  python scripts/full_size_graph_parity.py [C2 C3 C5 C4_4M C4]
+  python scripts/full_size_graph_parity.py [C2 C3 C5 C4_4M C4]      (DATA=overlap|clustered overrides the data kind)
+
+Round 5: C4 at its real 10M (the oracle's wave-order reduction in AVX2, prefetch hints, a visited bitset and a
+link phase spread over the threads by target brought its build inside one gpurun call); C4 / C5 on `overlap` data,
+the distribution their bench lines are taken on.
 """
 import json
 import os
@@ -26,7 +30,7 @@ from oracle import orc  # noqa: E402
 
 CFG = {"C2": ("cosine", 1_000_000, 768, 16, 100), "C3": ("euclidean", 1_000_000, 768, 32, 200),
        "C4": ("cosine", 10_000_000, 128, 16, 100), "C5": ("hamming", 5_000_000, 1024, 16, 64),
-       # C4's shape at 40 % of its size: what the oracle finishes inside one gpurun call (C4 itself: > 30 min)
+       # C4's shape at 40 % of its size (round 4: all the oracle finished inside one gpurun call)
        "C4_4M": ("cosine", 4_000_000, 128, 16, 100)}
 
 
@@ -49,7 +53,7 @@ def main():
     # On the GPU box only gpurun_out/ travels back, and it starts empty there: a run of SOME configs starts from
     # the committed file (profiles/ travels with the snapshot) and adds to it, so copying the result back to
     # profiles/ never drops the entries of an earlier call (round 3 lost three of four that way).
-    name = "r04_full_size_graph_parity.json"
+    name = "r05_full_size_graph_parity.json"
     out_path = os.environ.get("OUT", os.path.join(ROOT, "gpurun_out", name))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     out = {}
@@ -61,7 +65,8 @@ def main():
     for name in which:
         mname, n, dim, M, ef = CFG[name]
         metric = {"cosine": H.COSINE, "euclidean": H.EUCLIDEAN, "hamming": H.HAMMING}[mname]
-        x = gen_data(torch, n, dim, "clustered", 42, dev).cpu().numpy()
+        kind = os.environ.get("DATA") or ("overlap" if name in ("C4", "C5", "C4_4M") else "clustered")
+        x = gen_data(torch, n, dim, kind, 42, dev).cpu().numpy()
         items = H.ItemSet.from_f32(metric, x)
         del x
         levels = H.draw_levels(42, M, n)  # what hny_build draws from StdRng::seed_from_u64(42)
@@ -78,7 +83,7 @@ def main():
         same = (np.array_equal(g.rec_item, o.rec_item) and np.array_equal(g.rec_layer, o.rec_layer)
                 and np.array_equal(g.offsets, o.offsets) and np.array_equal(g.nbrs, o.nbrs)
                 and g.entry_points.tolist() == o.entry_points.tolist() and g.max_level == o.max_level)
-        res = {"config": f"{name}: {n} x {dim} {mname}, M={M} M0={2 * M} efC={ef}, clustered synthetic data, seed 42, default schedule (batch_max {bmax})",
+        res = {"config": f"{name}: {n} x {dim} {mname}, M={M} M0={2 * M} efC={ef}, {kind} synthetic data, seed 42, default schedule (batch_max {bmax})",
                "graphs_identical": bool(same), "records": int(len(g.rec_item)), "links": int(len(g.nbrs)),
                "n_links_added": [int(g.n_links_added), int(o.n_links_added)],
                "n_evals_walk": [int(g.n_evals_walk), int(o.n_evals_walk)],

@@ -1607,19 +1607,61 @@ def test_m_beyond_64_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0,
 
 
 def test_m0_limits_are_refused_loudly(orc, hny):
-    """include/hannoy_amd.h: M <= M0 <= 1024 (strict mode too since round 4: fresh builds; a strict-mode UPDATE of
-    lists beyond 64 slots stays refused): HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
+    """include/hannoy_amd.h: M <= M0 <= 1024 (strict mode too — fresh builds since round 4, updates since round 5):
+    HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
     v = np.random.default_rng(1).uniform(-1, 1, (500, 32)).astype(np.float32)
     items = hny.ItemSet.from_f32(hny.COSINE, v)
     for kw in (dict(M=16, M0=1025), dict(M=1025, M0=1025)):
         with pytest.raises(hny.HannoyError) as e:
             hny.build(items, ef_construction=32, **kw)
         assert e.value.code == -5
-    g = hny.build(items, M=16, M0=96, ef_construction=32, x86_order=True, batch_max=1)
-    with pytest.raises(hny.HannoyError) as e:
-        hny.build_incremental(items, g, to_insert=np.arange(10, dtype=np.uint32), to_delete=np.arange(10, 20, dtype=np.uint32),
-                              M=16, M0=96, ef_construction=32, x86_order=True, batch_max=1)
-    assert e.value.code == -5
+    with pytest.raises(hny.HannoyError) as e:  # unknown schedule bits are refused, not ignored
+        hny.build(items, M=16, M0=32, ef_construction=32, schedule=8)
+    assert e.value.code == -1
+
+
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,bmax", [(1, 700, 40, 16, 768, 48, 1), (0, 900, 33, 16, 768, 32, 64),
+                                                     (2, 600, 24, 8, 96, 40, 1)])
+def test_strict_mode_updates_of_lists_beyond_64_slots_equal_x86_oracle(orc, hny, metric, n, dim, M, M0, ef, bmax):
+    """The reference's fuzz configuration — build::<16, 768> WITH add / delete rounds (src/tests/fuzz.rs:86-87,143) —
+    in the reference's own arithmetic: strict mode (x86 summation order), sequential (batch_max = 1) and batched.
+    Round 4 refused a strict-mode update of lists beyond 64 slots (k_fill_gaps keeps one lane per slot); round 5 runs
+    fill_gaps_from_deleted on k_fill_gaps_wg with the one-wave prune (dist_rows in the x86 order) inside.  Three
+    update rounds with deletions, overwrites and additions, each == the oracle in ORC_ORDER_X86, record for record."""
+    rng = np.random.default_rng(11 * n + M0)
+    vecs = {i: rng.uniform(-1, 1, dim).astype(np.float32) for i in range(n)}
+
+    def mk(levels):
+        ids = np.array(sorted(vecs), np.uint32)
+        return orc.Dataset.from_f32(metric, np.stack([vecs[int(i)] for i in ids]), levels, ids)
+    kw = dict(batch_frac=1.0 if bmax > 1 else 0.0, batch_max=bmax)
+    kwo = dict(batch_frac=kw["batch_frac"], batch_max=0 if bmax == 1 else bmax)
+    ds = mk(draw_levels(n, M, seed=3))
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, **kwo)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, x86_order=True, **kw)
+    _same_graph(g, o)
+    assert max(len(v) for (i, l), v in o.as_dict().items() if l == 0) > 64  # layer-0 lists beyond one wave's lanes
+    nxt = n
+    for rnd in range(3):
+        live = sorted(vecs)
+        to_delete = sorted(rng.choice(live, len(live) // 8, replace=False).tolist())
+        for i in to_delete:
+            del vecs[i]
+        live = sorted(vecs)
+        overwrite = sorted(rng.choice(live, len(live) // 20, replace=False).tolist())
+        fresh = list(range(nxt, nxt + n // 6))
+        nxt += n // 6
+        for i in overwrite + fresh:
+            vecs[i] = rng.uniform(-1, 1, dim).astype(np.float32)
+        to_insert = sorted(overwrite + fresh)
+        lv = draw_levels(len(to_insert), M, seed=20 + rnd)
+        ds2 = mk(np.zeros(len(vecs), np.uint8))
+        items2 = hny.ItemSet(metric, dim, ds2.ids, ds2.codes, ds2.headers, lv)
+        o = orc.build_incremental(ds2, o, to_insert, lv, to_delete, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, **kwo)
+        g = hny.build_incremental(items2, g, to_insert, to_delete, M=M, M0=M0, ef_construction=ef, x86_order=True, **kw)
+        _same_graph(g, o)
+        assert g.n_links_added == o.n_links_added
 
 
 def test_kat9_reference_snapshots_on_the_gpu(orc, hny):

@@ -240,3 +240,27 @@ def test_kat9_100x30_snapshots(orc, kat9):
     ids, lv = orc.rust_sort_levels(np.arange(k["n"]), lv1)
     assert ids[0] == 65 and (np.diff(lv.astype(np.int64)) <= 0).all() and sorted(ids.tolist()) == list(range(k["n"]))
     assert ids.tolist() != sorted(ids.tolist(), key=lambda i: (-int(lv1[i]), i))
+
+
+def test_wave_order_avx_form_equals_its_scalar_statement(orc):
+    """The oracle's WAVE-order reduction has an AVX2 form (8 lanes of the group per register, round 5: the 10M-item
+    parity run spends its time there) next to the scalar statement of the order.  Both must give the same bits for
+    every op, over dims that exercise every lanes-per-row / chunks-per-lane shape and the zero padding, including
+    signed zeros, denormals and large magnitudes."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_wave_reduce_both.argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(12)
+    dims = list(range(1, 70)) + [96, 100, 127, 128, 129, 200, 255, 256, 257, 333, 511, 512, 513, 767, 768, 769, 1000,
+                                 1024, 1025, 1536, 2047, 2048, 3000, 4095, 4096]
+    out = np.zeros(2, np.float32)
+    for dim in dims:
+        for scale in (1.0, 1e-20, 1e18):
+            a = (rng.standard_normal(dim) * scale).astype(np.float32)
+            b = (rng.standard_normal(dim) * scale).astype(np.float32)
+            if dim > 3:
+                a[rng.integers(0, dim)] = -0.0
+                b[rng.integers(0, dim)] = 0.0
+            for op in (0, 1, 2):
+                L.orc_wave_reduce_both(op, dim, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+                assert out[:1].view(np.uint32)[0] == out[1:].view(np.uint32)[0], (dim, scale, op, out)
