@@ -190,11 +190,11 @@ def brute_force_topk(torch, metric, data, queries, k, chunk=1 << 20):
     """Exact top-k under the reference's metric definition (plumbing, torch on the GPU).
 
     The items are scored in pieces of `chunk` rows and the per-piece top-(k+32) merged, then re-ranked in f64.
-    Rounds 1-4 scored all items with ONE f32 GEMM per 256 queries: beyond 2^31 score elements (n > 8.39 M, i.e.
-    C4's 10M x 128) that GEMM / top-k returns garbage for part of the matrix on this stack, and the "truth" held
-    ~12 % wrong neighbours — the recall plateau of 0.84 - 0.88 "whatever the beam width" that rounds 3-4 reported
-    for every 10M index, GPU- or CPU-built, was this function (scripts/r5_truth_diag.py: the same index scores
-    1.0 against an exact f64 truth and 0.8799 against the old one)."""
+    Rounds 1-4 scored all items with ONE f32 GEMM per 256 queries: beyond 2^32 bytes of scores (n > 4.19 M: C4's
+    10M x 128, C5's 5M codes) that GEMM / top-k returns garbage for part of the matrix on this stack, and the
+    "truth" held ~12 % wrong neighbours — the recall plateau of 0.84 - 0.88 "whatever the beam width" that rounds
+    3-4 reported for every 10M index, GPU- or CPU-built, was this function (scripts/r5_truth_diag.py: the same
+    index scores 1.0 against an exact f64 truth and 0.8799 against the old one)."""
     nq, n = queries.shape[0], data.shape[0]
     kk = min(n, k + 32)
     dev = data.device
