@@ -33,7 +33,7 @@ EXPORTED = [
     "hny_lmdb_open", "hny_lmdb_stat_get", "hny_lmdb_get", "hny_lmdb_scan", "hny_lmdb_close",
     "hny_multi_builder_create", "hny_multi_builder_run", "hny_multi_builder_set_profiling",
     "hny_multi_builder_world", "hny_multi_builder_collectives", "hny_multi_builder_replica",
-    "hny_multi_builder_destroy", "hny_abi_sizes",
+    "hny_multi_builder_destroy", "hny_abi_sizes", "hny_set_graph_cache",
 ]
 ERR_IO = -9
 NNS_NONE = 0xFFFFFFFF  # by_item: the reference returns None
@@ -278,6 +278,14 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_graph_cache(max_bytes):
+    """hny_set_graph_cache: opt-in recycling of released export arrays (0 = off, the default)"""
+    L = load_library()
+    L.hny_set_graph_cache.restype = None
+    L.hny_set_graph_cache.argtypes = [C.c_size_t]
+    L.hny_set_graph_cache(int(max_bytes))
 
 
 def default_batch_max(n_items):

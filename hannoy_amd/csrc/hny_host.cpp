@@ -1259,6 +1259,14 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     w.queue = queue;
     w.res_global = b->d_res_global.p; // null unless the result sets outgrow the LDS (res_capacity)
     vis_buckets_for(b, w);
+    {
+      // one-chunk register beam (k_walk<.., RC = 1>, rows <= 512 B): no result set of this builder's walks exceeds 64
+      // entries — ef, the entry points (all pushed without a capacity check), a top layer that only grows
+      const uint64_t neps = b->entry_points.size();
+      const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(b->o.ef_construction, neps),
+                                               neps > 1 ? std::max<uint64_t>(b->top_layer_nodes, neps) : 0);
+      w.rb_one = most <= 64 && b->o.M <= 64 && env_int("HNY_RB_ONE", 1) != 0;
+    }
     return w;
   };
   auto prune_args = [&](int32_t l, uint32_t clo, uint32_t chi) {
@@ -1574,9 +1582,62 @@ static int device_error_words(hny_builder *b, const u64 *stats) {
   return HNY_OK;
 }
 
+// Export arrays released by hny_graph_free, kept for the next export — OFF unless the caller asks for it
+// (hny_set_graph_cache): a service that rebuilds in a loop saves the munmap of the old arrays and the first touch of
+// the new ones (C4: 1.4 GB each way, ~100 ms per build); anybody else gets plain malloc / free and holds nothing.
+namespace {
+struct GraphBufCache {
+  std::mutex mu;
+  size_t limit = 0; // bytes the cache may hold; 0 = off
+  void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+  size_t held() const { return cap[0] + cap[1] + cap[2] + cap[3]; }
+  void drop_all() {
+    for (int i = 0; i < 4; i++) {
+      free(p[i]);
+      p[i] = nullptr;
+      cap[i] = 0;
+    }
+  }
+  ~GraphBufCache() { drop_all(); }
+} g_gcache;
+// a cached array of at least `bytes` (and not more than twice that), or null
+void *gcache_take(int slot, size_t bytes, size_t *cap_out) {
+  std::lock_guard<std::mutex> lk(g_gcache.mu);
+  if (g_gcache.p[slot] && g_gcache.cap[slot] >= bytes && g_gcache.cap[slot] / 2 <= bytes + ((size_t)1 << 20)) {
+    void *q = g_gcache.p[slot];
+    *cap_out = g_gcache.cap[slot];
+    g_gcache.p[slot] = nullptr;
+    g_gcache.cap[slot] = 0;
+    return q;
+  }
+  return nullptr;
+}
+void gcache_release(int slot, void *q) {
+  if (!q) return;
+  void *drop = q;
+  {
+    std::lock_guard<std::mutex> lk(g_gcache.mu);
+    const size_t cap = g_gcache.limit ? malloc_usable_size(q) : 0;
+    if (cap >= ((size_t)1 << 20) && cap > g_gcache.cap[slot] && g_gcache.held() - g_gcache.cap[slot] + cap <= g_gcache.limit) {
+      drop = g_gcache.p[slot];
+      g_gcache.p[slot] = q;
+      g_gcache.cap[slot] = cap;
+    }
+  }
+  free(drop);
+}
+} // namespace
+void hny_set_graph_cache(size_t max_bytes) {
+  std::lock_guard<std::mutex> lk(g_gcache.mu);
+  g_gcache.limit = max_bytes;
+  if (g_gcache.held() > max_bytes) g_gcache.drop_all();
+}
+
 // Prepare the export arrays of the build that is starting (hny_builder.xbuf): sizes are upper bounds known when
-// the builder is created (which records exist never changes; a list holds at most its cap), finish() trims the
-// neighbour array to what the lists really hold.
+// the builder is created (which records exist never changes; a list holds at most its cap).  The neighbour array
+// keeps its prepared capacity (handing the unused tail back costs a munmap of touched pages, as much as the first
+// touch saved); hny_graph_free returns all of it.
 static void start_export_prefault(hny_builder *b) {
   if (!b->will_export) return;
   b->xbuf.join();
@@ -1584,8 +1645,18 @@ static void start_export_prefault(hny_builder *b) {
                           (size_t)(b->nrec_bound + 1) * 8, (size_t)std::max<uint64_t>(b->nbr_bound, 1) * 4};
   if (want[0] + want[1] + want[2] + want[3] < ((size_t)8 << 20)) return; // small: finish() allocates
   bool have = true;
-  for (int i = 0; i < 4; i++) have = have && b->xbuf.p[i] && b->xbuf.cap[i] >= want[i];
-  if (have) return; // a build that was reset before its finish(): the arrays are still here, and touched
+  for (int i = 0; i < 4; i++) {
+    if (!(b->xbuf.p[i] && b->xbuf.cap[i] >= want[i])) { // (else: a build reset before its finish() left it here)
+      size_t cap = 0;
+      if (void *q = gcache_take(i, want[i], &cap)) { // released by an earlier graph: allocated and touched already
+        free(b->xbuf.p[i]);
+        b->xbuf.p[i] = q;
+        b->xbuf.cap[i] = cap;
+      }
+    }
+    have = have && b->xbuf.p[i] && b->xbuf.cap[i] >= want[i];
+  }
+  if (have) return;
   auto *x = &b->xbuf;
   x->th = std::thread([x, want]() {
     for (int i = 0; i < 4; i++) {
@@ -1607,15 +1678,17 @@ static void *take_export_buf(hny_builder *b, int slot, size_t bytes) {
     b->xbuf.cap[slot] = 0;
     return q;
   }
+  size_t cap = 0;
+  if (void *q = gcache_take(slot, bytes, &cap)) return q;
   return malloc(bytes);
 }
 
 void hny_graph_free(hny_graph *g) {
   if (!g) return;
-  free((void *)g->rec_item);
-  free((void *)g->rec_layer);
-  free((void *)g->rec_offset);
-  free((void *)g->neighbours);
+  gcache_release(0, (void *)g->rec_item);
+  gcache_release(1, (void *)g->rec_layer);
+  gcache_release(2, (void *)g->rec_offset);
+  gcache_release(3, (void *)g->neighbours);
   free((void *)g->entry_points);
   free(g);
 }
@@ -1761,8 +1834,6 @@ int hny_builder_finish(hny_builder *b, hny_graph **out) {
       }
     }
   });
-  // the prepared array was sized for full lists: hand the unused tail back (in place for blocks of this size)
-  if (void *shrunk = realloc(nbrs, std::max<uint64_t>(rec_off[nrec], 1) * 4)) g->neighbours = nbrs = (uint32_t *)shrunk;
   uint32_t *eps = (uint32_t *)malloc(std::max<size_t>(b->entry_points.size(), 1) * 4);
   for (size_t i = 0; i < b->entry_points.size(); i++) eps[i] = b->ids[b->entry_points[i]];
   g->n_records = nrec;

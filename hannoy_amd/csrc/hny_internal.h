@@ -136,6 +136,7 @@ struct WalkArgs {
   // (VisB in hny_kernels.hip); vis_magic = floor(2^vis_shift / vis_buckets) + 1 with vis_shift = 31 + floor(log2 buckets)
   // (the magic then fits 32 bits and x div buckets == (x * magic) >> vis_shift for x < 2^30); vis_smask = 2^k - 1 >= n - 1
   u32 vis_buckets, vis_magic, vis_shift, vis_smask;
+  u32 rb_one;        // build walks on rows <= 512 B: no result set of this builder exceeds 64 entries -> one-chunk register beam
 };
 
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369 with `candidates`, 642-711,

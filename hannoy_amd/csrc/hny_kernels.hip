@@ -1553,11 +1553,11 @@ __device__ __forceinline__ u32 row_shr(u32 v) {
   else return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xF, 0xF, false);
 }
 
-template <int LPRO>
+template <int LPRO, int RC>
 __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4 (&q)[LPRO / 8], float qn, u32 layer,
                                                  int ef, const u32 *eps, int n_eps, Beam &s, Visited &vis,
                                                  const VisB &vb, u32 *nb_ids, float *nb_d, u64 &evals, u32 &err_iter,
-                                                 BeamR<2> &rb) {
+                                                 BeamR<RC> &rb) {
   const int ln = HNY_LANE, t = ln & 7;
   const u64 lt = (1ull << ln) - 1ull;
   u32 *dump = reinterpret_cast<u32 *>(nb_d); // 64 words behind nb_ids: where the lanes without a new id write
@@ -1566,6 +1566,12 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
   s.n_weird = 0;
   s.tie_bits = 0;
   s.dropped = false;
+  // this layer's lists (nbr_ids, resolved once per walk instead of once per expansion: the expansion loop then
+  // carries base / stride / cap / index table instead of l0_ids, M0, up_ids, up_layers, M, upper_idx and layer)
+  const u32 *const lst_base = layer == 0 ? g.l0_ids : g.up_ids + (size_t)(layer - 1u) * g.M;
+  const u32 lst_stride = layer == 0 ? g.M0 : g.up_layers * g.M;
+  const u32 lst_cap = layer == 0 ? g.M0 : g.M;
+  const int *const lst_idx = layer == 0 ? nullptr : g.upper_idx;
   // :474-481 every entry point goes to candidates and res (no capacity check) and is visited
   {
     const int ne = n_eps; // <= 64 here
@@ -1584,7 +1590,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     WSYNC();
     for (int r = 0; r < ne; r++) {
       const u64 key = ((u64)uni(dump[r]) << 32) | ((u64)uni(nb_ids[r]) << 1);
-      beam_insert_rb<2>(s, rb, key, 0x7FFFFFFF);
+      beam_insert_rb<RC>(s, rb, key, 0x7FFFFFFF);
     }
     WSYNC();
   }
@@ -1603,19 +1609,21 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     // ---- candidates.peek()/pop(): smallest distance bits, larger id first among equals
     // (BinaryHeap<(Reverse<OrderedFloat>, ItemId)>, :469, :483-488)
     const int len = s.res_len;
-    const bool un0 = ln < len && !(rb.r[0] & 1ull), un1 = ln + 64 < len && !(rb.r[1] & 1ull);
-    const u64 m0 = ballot(un0), m1 = ballot(un1);
-    const u32 dmax = (u32)(rb_get<2>(rb, len - 1) >> 32);
+    // (RC == 1: a beam of at most 64 entries, ef <= 64 — every "second chunk" term below folds away)
+    const bool un0 = ln < len && !(rb.r[0] & 1ull), un1 = RC > 1 && ln + 64 < len && !(rb.r[RC - 1] & 1ull);
+    const u64 m0 = ballot(un0), m1 = RC > 1 ? ballot(un1) : 0ull;
+    const u32 dmax = (u32)(rb_get<RC>(rb, len - 1) >> 32);
     const bool have_a = (m0 | m1) != 0ull;
     int last = -1;
     u32 d0 = 0u;
     u64 ta = ~0ull;
     if (have_a) { // pop-order key: distance bits ascending, then id DESCENDING
       const int first_un = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
-      d0 = (u32)(rb_get<2>(rb, first_un) >> 32);
-      const u64 t0 = ballot(un0 && (u32)(rb.r[0] >> 32) == d0), t1 = ballot(un1 && (u32)(rb.r[1] >> 32) == d0);
+      d0 = (u32)(rb_get<RC>(rb, first_un) >> 32);
+      const u64 t0 = ballot(un0 && (u32)(rb.r[0] >> 32) == d0),
+                t1 = RC > 1 ? ballot(un1 && (u32)(rb.r[RC - 1] >> 32) == d0) : 0ull;
       last = t1 ? 64 + 63 - __clzll((long long)t1) : 63 - __clzll((long long)t0);
-      ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get<2>(rb, last) & 0xFFFFFFFEull));
+      ta = ((u64)d0 << 32) | (u64)(~(u32)(rb_get<RC>(rb, last) & 0xFFFFFFFEull));
     }
     u64 tp = ~0ull;
     int pi = -1;
@@ -1655,16 +1663,17 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
       WSYNC();
       settle(s);
     } else {
-      cslot = (u32)(rb_get<2>(rb, last) >> 1) & 0x7FFFFFFFu;
+      cslot = (u32)(rb_get<RC>(rb, last) >> 1) & 0x7FFFFFFFu;
       rb.r[0] |= (u64)(ln == last);
-      rb.r[1] |= (u64)(ln + 64 == last);
+      if constexpr (RC > 1) rb.r[1] |= (u64)(ln + 64 == last);
     }
     const float fmax = __uint_as_float(dmax); // f_max captured once per pop (:484)
     PH_STAMP(s, 0);
 
     // ---- neighbours of c (:491-495): the in-memory list (fresh build), one lane per slot
-    u32 cap;
-    const u32 *nl = nbr_ids(g, layer, cslot, cap);
+    const u32 cap = lst_cap;
+    const u32 node = lst_idx ? (u32)lst_idx[cslot] : cslot;
+    const u32 *nl = lst_base + (size_t)node * lst_stride;
     u32 id = nl[(u32)ln < cap ? (u32)ln : cap - 1u];
     const bool valid = (u32)ln < cap && id != HNY_SENT;
 #ifdef HNY_PHASE_CLOCKS
@@ -1735,7 +1744,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
     s.ph[8]++;
 #endif
     if (__popcll(amask) >= HNY_RB_MERGE_MIN && HNY_RB_MERGE) { // one key: the plain insert is cheaper
-      beam_merge_rb<2>(s, rb, acc != 0u, ((u64)khi << 32) | (u64)klo, ef);
+      beam_merge_rb<RC>(s, rb, acc != 0u, ((u64)khi << 32) | (u64)klo, ef);
       amask = 0ull;
     }
     while (amask) {
@@ -1743,7 +1752,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
       amask &= amask - 1ull;
       const u32 db = (u32)__builtin_amdgcn_readlane((int)khi, r);
       const u32 idr = (u32)__builtin_amdgcn_readlane((int)klo, r);
-      beam_insert_rb<2>(s, rb, ((u64)db << 32) | (u64)idr, ef);
+      beam_insert_rb<RC>(s, rb, ((u64)db << 32) | (u64)idr, ef);
     }
     PH_STAMP(s, 3);
   }
@@ -1764,7 +1773,7 @@ __device__ __forceinline__ void walk_layer_short(const GraphDev &g, const float4
 #define HNY_WALK_WPE_SMALL 6
 #endif
 template <int LPR, int NCH, bool BIG_EPS, int SP, bool RM = false, int RC = 0>
-__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <= 32 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
+__global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC == 2) && LPR <= 32 ? HNY_WALK_WPE_SMALL : HNY_WALK_WPE)) void k_walk(GraphDev g_in, WalkArgs a_in) {
   constexpr bool RB = RC != 0;
   constexpr int RCN = RC ? RC : 1;
   static_assert(!(RB && (BIG_EPS || SP == 0)), "register beam: specialised kernels only");
@@ -1777,12 +1786,22 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
 #ifdef HNY_NO_SHORT_WALK
   constexpr bool SHORT = false;
 #else
-  constexpr bool SHORT = SP != 0 && RC == 2 && NCH == 1 && LPR <= 32;
+  constexpr bool SHORT = SP != 0 && (RC == 1 || RC == 2) && NCH == 1 && LPR <= 32;
 #endif
   GraphDev g = g_in;
-  WalkArgs a = a_in;
   specialize<SP>(g);
-  if constexpr (SP != 0) a.reader_mode = RM ? 1 : 0; // RM: the Reader's search (hny_builder_search_knn)
+  // The ~70 scalars of WalkArgs are read where they are used, from the kernarg segment, through a pointer the
+  // compiler cannot see through (KA_FRESH: an empty asm that redefines it).  As a by-value copy they were all live
+  // across the expansion loop — which uses a handful of them — and the register allocator parked 106 SGPRs in the
+  // lanes of two VGPRs (v_writelane / v_readlane: ~20 reloads per expansion on the vector port, and two VGPRs of
+  // an 80-VGPR budget).  After a KA_FRESH a field is an s_load from the scalar cache at its next use.
+  typedef const WalkArgs __attribute__((address_space(4))) *KArgs;
+  KArgs ak = (KArgs)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() +
+                     ((sizeof(GraphDev) + alignof(WalkArgs) - 1) / alignof(WalkArgs)) * alignof(WalkArgs));
+  (void)a_in;
+#define a (*ak)
+#define KA_FRESH() asm volatile("" : "+s"(ak))
+  const int reader_mode = SP != 0 ? (RM ? 1 : 0) : a.reader_mode; // RM: the Reader's search (hny_builder_search_knn)
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
   u64 *pool = res + a.rcap;
@@ -1852,6 +1871,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
   // dynamic work queue: queries differ a lot in length, a static stride leaves a long launch tail
   u32 xq_dead = 0; // XCD-tiled queue: how many of the 8 counters this wave has found exhausted
   for (;;) {
+    KA_FRESH();
     u32 m = 0;
     if (ln == 0) {
       if (SP != 0 && a.xcd_tile) {
@@ -1934,10 +1954,11 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
       const bool last = (layer == a.layer);
       if (last && a.descend_only) break;
       if constexpr (SHORT)
-        walk_layer_short<LPR>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
+        walk_layer_short<LPR, RCN>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
       else
         walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
                                      nb_d, evals, err_iter, qrow, rb);
+      KA_FRESH();
       if (last) break;
       // :305-306 eps = [closest]
       const u32 closest = RB ? (u32)(rb_get<RCN>(rb, 0) >> 1) & 0x7FFFFFFFu : uni((u32)(s.res[0] >> 1) & 0x7FFFFFFFu);
@@ -1947,7 +1968,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
       lkey = (lkey << 16) | (u64)((u32)g.upper_idx[closest] & 0xFFFFu);
       // walk_layer owns a fresh visited set; Reader::hnsw_search shares `path` across the greedy
       // layers and clears it once before layer 0 (reader.rs:731-743)
-      if (!a.reader_mode || layer == a.layer + 1) {
+      if (!reader_mode || layer == a.layer + 1) {
         if (vis.log_over) log_over_cnt++;
         visited_clear(vis);
         visb_clear(vb);
@@ -1986,7 +2007,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
       }
     }
     int total = s.res_len;
-    if (a.reader_mode && total < (int)a.knn_k) {
+    if (reader_mode && total < (int)a.knn_k) {
       // Reader::hnsw_search exhaustive fallback (reader.rs:771-795): the walk got trapped in a
       // sub-graph with fewer than k items; restart from every item not seen yet (ascending id),
       // sharing the visited set, until opt.ef hits are collected.  Rare; written for clarity.
@@ -2017,9 +2038,10 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
         if (ln == 0) eps[0] = slot;
         WSYNC();
         if constexpr (SHORT)
-          walk_layer_short<LPR>(g, q, qn, 0u, ef2, eps, 1, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
+          walk_layer_short<LPR, RCN>(g, q, qn, 0u, ef2, eps, 1, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
         else
           walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
+        KA_FRESH();
         if (total + s.res_len > (int)a.rcap) {
           s.err = 1;
           break;
@@ -2056,7 +2078,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
       // a search whose tie pool overflowed: flagged instead of counted, the host repeats the query on the
       // heap-queue searcher (k_nns_filtered without a filter), which has no pool
       // (force_pool: tests send every k-th query that way)
-      if (a.reader_mode && a.pool_flag && (s.pool_over || (a.force_pool && m % a.force_pool == 0u))) {
+      if (reader_mode && a.pool_flag && (s.pool_over || (a.force_pool && m % a.force_pool == 0u))) {
         total = (int)0xFFFFFFFEu;
         s.pool_over = 0;
       }
@@ -2090,6 +2112,8 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && RC == 2 && LPR <
     if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
   }
 }
+#undef a
+#undef KA_FRESH
 
 // ---------------------------------------------------------------------------------------------
 // Reader::nns with a candidates filter and/or by_item (reader.rs:301-369, 642-711, 809-896).
@@ -4502,6 +4526,16 @@ struct Hot {
             // (a ONE-chunk register beam for ef <= 64 — every beam scan a single ballot — was measured on
             // C5: walk 0.692 s against 0.668 s with two chunks, i.e. no gain; the beam scans are not what
             // bounds the short-row walk)
+            if constexpr (C == 1 && L <= 32) {
+              // build walks on short rows whose result sets never exceed 64 entries (ef <= 64, few entry points —
+              // the host decides, WalkArgs.rb_one): ONE 64-entry chunk in registers.  Round 3 measured this form
+              // as no gain (0.692 against 0.668 s) while the walk was bound by its global atomics; on the
+              // issue-bound walk of round 5 every beam scan, merge rank and eviction round it halves counts.
+              if (!a.reader_mode && a.rb_one) {
+                hipLaunchKernelGGL((k_walk<L, C, false, SP, false, 1>), dim3(grid), dim3(64), lds, st, g, a);
+                return hipGetLastError();
+              }
+            }
             if (a.reader_mode)
               hipLaunchKernelGGL((k_walk<L, C, false, SP, true, 2>), dim3(grid), dim3(64), lds, st, g, a);
             else

@@ -162,6 +162,14 @@ typedef struct {
 /* ---- one-call build: replaces HnswBuilder::build (hnsw.rs:122-216) ---- */
 int hny_build(const hny_build_opts *opts, const hny_items *items, hny_graph **out);
 void hny_graph_free(hny_graph *g);
+/* Opt-in recycling of the four large arrays of an exported graph, 1.4 GB at C4: with max_bytes > 0, hny_graph_free keeps
+ * them (at most max_bytes in total, process-wide) for the next export instead of returning them to the system — a
+ * caller that rebuilds in a loop saves the munmap of the old arrays and the first touch of the new ones (~100 ms
+ * per C4 build).  0 (the default) turns it off and releases what is held: nothing stays resident behind the
+ * caller's back.  Independent of this, a builder allocates and touches its export arrays on a helper thread while
+ * the device builds, so a one-off build does not pay their first touch either; the neighbour array keeps the
+ * capacity of full lists until hny_graph_free. */
+void hny_set_graph_cache(size_t max_bytes);
 
 /* ---- incremental build: HnswBuilder::build on a non-empty index (hnsw.rs:122-216 with
  * prepare_levels_and_entry_points' deletion branch :236-289, on-disk links in get_neighbours

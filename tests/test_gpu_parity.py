@@ -1606,6 +1606,33 @@ def test_m_beyond_64_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0,
     _same_graph(g3, o)
 
 
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,flat", [(3, 20000, 1024, 16, 32, 64, False), (0, 12000, 128, 16, 32, 64, False),
+                                                        (3, 60, 512, 8, 16, 16, True), (4, 64, 256, 8, 16, 3, True),
+                                                        (1, 70, 100, 8, 16, 16, True), (3, 6000, 256, 12, 24, 40, False)])
+def test_one_chunk_register_beam_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, ef, flat):
+    """Build walks on rows of at most 512 B whose result sets never exceed 64 entries keep the beam in ONE 64-entry
+    register chunk (k_walk<.., RC = 1>, WalkArgs.rb_one; round 5).  ef = 64 fills the chunk to its last lane; `flat`
+    puts every item on level 0, so all n items are entry points and res starts above ef (it then only grows: 60 and
+    64 entry points still fit, 70 take the two-chunk kernel).  Same graph, same counters as the oracle and as the
+    two-chunk kernel (HNY_RB_ONE=0)."""
+    rng = np.random.default_rng(5 * n + dim)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    levels = np.zeros(n, np.uint8) if flat else draw_levels(n, M, seed=n)
+    ds, items = _mk(orc, hny, metric, vecs, levels)
+    kw = dict(batch_frac=0.5, batch_max=4096)
+    o = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_WAVE, threads=8, **kw)
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g, o)
+    assert (g.n_links_added, g.n_evals_walk) == (o.n_links_added, o.n_evals_walk)
+    monkeypatch.setenv("HNY_RB_ONE", "0")
+    g2 = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g2, o)
+    assert (g2.n_evals_walk, g2.n_evals_prune, g2.n_evals_apply) == (g.n_evals_walk, g.n_evals_prune, g.n_evals_apply)
+    monkeypatch.setenv("HNY_RB_ONE", "1")
+    monkeypatch.setenv("HNY_POOL_FORCE_RETRY", "3")  # and with every third member through the heap walk
+    _same_graph(hny.build(items, M=M, M0=M0, ef_construction=ef, **kw), o)
+
+
 def test_m0_limits_are_refused_loudly(orc, hny):
     """include/hannoy_amd.h: M <= M0 <= 1024 (strict mode too — fresh builds since round 4, updates since round 5):
     HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
@@ -1620,8 +1647,8 @@ def test_m0_limits_are_refused_loudly(orc, hny):
     assert e.value.code == -1
 
 
-@pytest.mark.parametrize("metric,n,dim,M,M0,ef,bmax", [(1, 700, 40, 16, 768, 48, 1), (0, 900, 33, 16, 768, 32, 64),
-                                                     (2, 600, 24, 8, 96, 40, 1)])
+@pytest.mark.parametrize("metric,n,dim,M,M0,ef,bmax", [(1, 2500, 40, 16, 768, 120, 1), (0, 2500, 33, 16, 768, 100, 64),
+                                                     (2, 2000, 24, 8, 96, 90, 1)])
 def test_strict_mode_updates_of_lists_beyond_64_slots_equal_x86_oracle(orc, hny, metric, n, dim, M, M0, ef, bmax):
     """The reference's fuzz configuration — build::<16, 768> WITH add / delete rounds (src/tests/fuzz.rs:86-87,143) —
     in the reference's own arithmetic: strict mode (x86 summation order), sequential (batch_max = 1) and batched.
