@@ -2385,7 +2385,10 @@ static int nns_impl(hny_builder *b, const hny_query_opts *qo, uint64_t nq, const
     return fail(HNY_ERR_UNSUPPORTED, "ef_search %u: result sets hold at most %u entries", ef, HNY_RES_GLOBAL_MAX - 1);
   // k_nns_filtered keeps its result set in LDS (up to 4 096 entries); beyond that the same search runs with
   // `res` as a heap in HBM next to the search queue's (k_nns_heap)
-  const bool big = ef + 1 > HNY_RES_LDS_MAX;
+  // ... and so does a search that starts from more entry points than the LDS set holds (every entry point is pushed
+  // to `res` without a capacity check, reader.rs:755-761: an all-level-0 index of 4 096 - 8 192 items)
+  const uint64_t eps_need = std::max<uint64_t>(b->entry_points.size(), b->entry_points.size() > 1 ? b->top_layer_nodes : 0) + 1;
+  const bool big = ef + 1 > HNY_RES_LDS_MAX || eps_need > HNY_RES_LDS_MAX;
   HIP_TRY(hipSetDevice(b->device));
   const uint32_t n = b->n;
   auto exists = [&](uint32_t s) { return !b->incremental || !b->deleted[s]; };

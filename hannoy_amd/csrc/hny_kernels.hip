@@ -3488,12 +3488,16 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, const u64 *list,
       }
       const float d0 = dist8<LPRO>(g, c, r0, cn, s_norm[j]);
       bool v = fbits(d0 * g.alpha) < cdb; // hnsw.rs:585
+      // the counter is the reference's count (a candidate stops at its first violating row), not the work done:
+      // row j + 1 is computed for every open candidate, but counted only for those row j did not reject
+      u64 counted = open;
       if (two) {
+        counted = ballot(have && !viol && !v);
         const float d1 = dist8<LPRO>(g, c, r1, cn, s_norm[j + 1]);
         v = v || fbits(d1 * g.alpha) < cdb;
       }
       viol = viol || v;
-      evals += (u64)((__popcll(open) >> 3) << (two ? 1 : 0));
+      evals += (u64)(__popcll(open) >> 3) + (two ? (u64)(__popcll(counted) >> 3) : 0ull);
     }
     // (3) the survivors, in candidate order
     u64 sv = ballot(have && !viol && t == 0);

@@ -138,7 +138,11 @@ typedef struct {
   uint32_t max_level;
   uint64_t n_links_added;     /* BuildStats.n_links_added */
   uint64_t n_distance_evals;  /* distance evaluations performed on the device */
-  uint64_t n_evals_walk, n_evals_prune, n_evals_apply;
+  uint64_t n_evals_walk, n_evals_prune, n_evals_apply; /* n_evals_walk is the reference's count (hnsw.rs:476,503 call
+                              * sites; every parity test compares it with the oracle's).  The other two count what the
+                              * kernels computed: robust_prune tests several candidates at once (the one-wave kernel
+                              * for rows <= 512 B still counts a candidate only up to its first violating row), and
+                              * add_link skips the re-prunes of lists already known to prune to themselves */
   uint64_t n_batches;
   double t_upload_s, t_build_s, t_export_s; /* host wall clock of the three phases */
   uint64_t n_tie_pool_overflow; /* always 0 in a returned graph: a walk whose tie pool overflows is repeated

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 out=gpurun_out/r2_c2
 rm -rf $out && mkdir -p $out
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu > $out/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu --alt-data none > $out/stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv") $out/kernel_stats.csv
 grep -a '"metric"' $out/stats.log | tail -1 > $out/bench_under_rocprof.json
 find $out -name "*kernel_trace.csv" -delete

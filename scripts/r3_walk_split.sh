@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 out=gpurun_out/r3_split
 rm -rf $out && mkdir -p $out
 ARGS=${ARGS:-"--items 5000000 --dim 1024 --metric hamming --ef 64"}
-timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $out/t -- python3 bench.py --no-cpu --no-recall --queries 0 --steps 1 --warmup 0 $ARGS > $out/run.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $out/t -- python3 bench.py --no-cpu --no-recall --queries 0 --steps 1 --warmup 0 --alt-data none $ARGS > $out/run.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/r3_split/t/**/*kernel_trace.csv", recursive=True)[0]

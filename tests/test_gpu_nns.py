@@ -246,3 +246,36 @@ def test_search_cancellation_through_the_c_abi(orc, hny):
             assert np.array_equal(dists[done].view(np.uint32), ref[1][done].view(np.uint32))
         else:
             assert done.all()
+
+
+@pytest.mark.parametrize("metric,n,dim", [(1, 6000, 16), (3, 4200, 128)])
+def test_filtered_and_by_item_search_from_more_entry_points_than_the_lds_set_holds(orc, hny, metric, n, dim):
+    """An all-level-0 index of more than 4 095 items: every item is an entry point (hnsw.rs:278-285) and every one
+    of them is pushed to `res` before the first pop (reader.rs:755-761), whatever ef_search says — k_nns_filtered's LDS
+    result set (4 096 entries) cannot hold them.  Round 4 accepted such builds (up to 8 192 entry points) but sent a
+    filtered / by_item search with a small ef to the LDS kernel; it now takes the heaps in HBM (k_nns_heap).  Same
+    ids, distances and counts as the restated Reader."""
+    rng = np.random.default_rng(n)
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ds = orc.Dataset.from_f32(metric, vecs, np.zeros(n, np.uint8))
+    items = hny.ItemSet(metric, dim, ds.ids, ds.codes, ds.headers, ds.levels)
+    qs, qc, qh = _queries(orc, metric, rng, 24, dim)
+    qi = np.concatenate([ds.ids[rng.integers(0, n, 24)], [10 ** 7]]).astype(np.uint32)
+    with hny.Builder(items, M=8, M0=16, ef_construction=24, batch_frac=0.5, batch_max=512) as b:
+        b.run()
+        g = b.finish()
+        assert len(g.entry_points) == n and g.max_level == 0
+        for frac_kept in (0.5, 0.02):
+            cand = ds.ids[rng.random(n) < frac_kept]
+            for k, ef in ((10, 50), (3, 2)):
+                got = b.nns(qc, qh, k=k, ef_search=ef, candidates=cand, linear_below=0)
+                want = orc.search(ds, g, qc, qh, k=k, ef_search=ef, order=orc.ORDER_WAVE, threads=8,
+                                  candidates=cand, linear_below=0)
+                _same(got, want)
+                got = b.nns(k=k, ef_search=ef, query_items=qi, candidates=cand, linear_below=0)
+                want = orc.search(ds, g, None, None, k=k, ef_search=ef, order=orc.ORDER_WAVE, threads=8,
+                                  query_items=qi, candidates=cand, linear_below=0)
+                _same(got, want)
+        got = b.nns(k=5, ef_search=20, query_items=qi)
+        want = orc.search(ds, g, None, None, k=5, ef_search=20, order=orc.ORDER_WAVE, threads=8, query_items=qi)
+        _same(got, want)
