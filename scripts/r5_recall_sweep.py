@@ -40,6 +40,9 @@ def main():
     p.add_argument("--queries", type=int, default=1000)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--tag", default="")
+    p.add_argument("--level-seeds", default="",
+                   help="comma-separated seeds of the level draw (default: --seed): every GPU / CPU build is repeated per "
+                        "seed on the SAME data and queries — the build-to-build spread of either side at fixed data")
     a = p.parse_args()
     c = dict(CONFIGS[a.config])
     if a.items:
@@ -92,10 +95,12 @@ def main():
         x = x_dev.cpu().numpy()
         del x_dev
         torch.cuda.empty_cache()
-        levels = H.draw_levels(a.seed, M, c["n"])
+        lseeds = [int(v) for v in a.level_seeds.split(",") if v != ""] or [a.seed]
+        levels = H.draw_levels(lseeds[0], M, c["n"])
         phase[0] = f"{kind}: encode"
         items = H.ItemSet.from_f32(metric, x, levels=levels)
         del x
+        out["level_seeds"] = lseeds
 
         def recalls(builder):
             r = {}
@@ -108,9 +113,12 @@ def main():
                     r[str(e) + "_tie_aware"] = round(float(ok.sum()) / (10 * len(kth)), 4)
             return r
 
-        for fr in fracs:
+        for lsd in lseeds:
+          levels = H.draw_levels(lsd, M, c["n"])
+          items.levels = levels
+          for fr in fracs:
             for bm in bmaxes:
-                phase[0] = f"{kind}: GPU build batch_max {bm} frac {fr}"
+                phase[0] = f"{kind}: GPU build batch_max {bm} frac {fr} level seed {lsd}"
                 kw = dict(M=M, M0=M0, ef_construction=ef, batch_frac=fr)
                 if bm:
                     kw["batch_max"] = bm
@@ -122,7 +130,7 @@ def main():
                     b.run()
                     g = b.finish()
                     dt = time.perf_counter() - t0
-                    rec = {"batch_max": bm or H.default_batch_max(c["n"]),
+                    rec = {"batch_max": bm or H.default_batch_max(c["n"]), "level_seed": lsd,
                            "default": bm == 0, "batch_frac": fr, "build_s": round(dt, 4),
                            "vec_per_s": round(c["n"] / dt, 1), "n_batches": int(g.n_batches),
                            "links": int(len(g.nbrs)), "evals_walk": int(g.n_evals_walk),
@@ -132,14 +140,17 @@ def main():
                 print(json.dumps({"data": kind, **rec}), flush=True)
                 save()
         if a.cpu_builds:
+          for lsd in lseeds:
+            levels = H.draw_levels(lsd, M, c["n"])
+            items.levels = levels
             ds = orc.Dataset(metric, c["dim"], items.ids, items.codes, items.headers, levels)
             for r_ in range(a.cpu_builds):
-                phase[0] = f"{kind}: CPU build {r_ + 1} of {a.cpu_builds} ({threads} threads)"
+                phase[0] = f"{kind}: CPU build {r_ + 1} of {a.cpu_builds} ({threads} threads), level seed {lsd}"
                 t0 = time.perf_counter()
                 og = orc.build(ds, M=M, M0=M0, ef=ef, order=orc.ORDER_X86, threads=threads)
                 dt = time.perf_counter() - t0
                 with H.Builder(items, prev=og, load=True, M=M, M0=M0, ef_construction=ef) as b:
-                    rec = {"run": r_ + 1, "threads": threads, "build_s": round(dt, 2),
+                    rec = {"run": r_ + 1, "level_seed": lsd, "threads": threads, "build_s": round(dt, 2),
                            "vec_per_s": round(c["n"] / dt, 1), "links": int(len(og.nbrs)), "recall_at_10": recalls(b)}
                 del og
                 out["cpu_builds"].append(rec)
