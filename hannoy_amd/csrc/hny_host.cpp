@@ -1284,6 +1284,10 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     p.cap_sel = cs;
     p.batch_level = L;
     p.list_global = b->rcap > HNY_RES_LDS_MAX ? 1u : 0u;
+    // neighbouring members of the long-row prune on one XCD, like the walk's tiles: k_prune_wg's L2 hit rate 0.12 ->
+    // 0.19, its fabric reads 368 -> 338 GB at C2 — and not a microsecond of its 66 ms (profiles/r05_prune_xcd_tile_fetch.txt:
+    // the workgroup prune is bound by its barriers and dependent chains, not by bytes)
+    p.xcd_tile = (u32)std::max(0, env_int("HNY_PRUNE_XCD_TILE", 512));
     return p;
   };
   auto launch_prune = [&](const PruneArgs &p, hipStream_t st) -> hipError_t {

@@ -189,6 +189,7 @@ struct PruneArgs {
   u32 sel_stride, cap_sel, batch_level;
   const u64 *perm;  // processing order (index -> member), or null
   u32 list_global;  // general kernels: candidate lists too long for LDS are pruned straight from `cand`
+  u32 xcd_tile;     // k_prune_wg, != 0: tiles of xcd_tile consecutive members (locality order) stay on one XCD
 };
 
 struct EmitArgs {

@@ -3347,7 +3347,22 @@ __global__ __launch_bounds__(NW * 64, wg_waves_per_simd(NCH, NW)) void k_prune_w
   WgPruneLds L = wg_prune_carve(smem + (list_global ? (size_t)0 : (size_t)a.rcap * 8), SL, g.row_stride, NW, wg_capmax(g));
   const int tid = threadIdx.x;
   u64 evals = 0;
-  for (u32 mi = a.lo + blockIdx.x; mi < a.hi; mi += gridDim.x) {
+  // Workgroups go to the XCDs round robin, so with member = blockIdx + k * gridDim neighbouring members (locality
+  // order: overlapping candidate sets) run at the same time on EIGHT different L2s.  xcd_tile != 0 (grid a multiple
+  // of 8): the members come in tiles of xcd_tile, tile k belongs to XCD k % 8, and workgroup b takes position
+  // b / 8 + k * gridDim / 8 of XCD b % 8's members — the workgroups resident on one XCD then prune neighbouring
+  // queries and find each other's candidate rows in their L2.  Members beyond the last full round of tiles keep
+  // the plain mapping.  Results are stored per member: only the traffic changes.
+  const u32 cnt_all = a.hi - a.lo;
+  const u32 T = a.xcd_tile && (gridDim.x & 7u) == 0u ? a.xcd_tile : 0u;
+  const u32 tiled = T ? cnt_all / (8u * T) * (8u * T) : 0u;
+  for (u32 v = blockIdx.x; v < cnt_all; v += gridDim.x) {
+    u32 idx = v;
+    if (v < tiled) {
+      const u32 x = v & 7u, p = v >> 3;
+      idx = ((p / T) * 8u + x) * T + (p % T);
+    }
+    const u32 mi = a.lo + idx;
     const u32 m = a.perm ? (u32)a.perm[mi - a.lo] : mi; // same locality order as the walk
     const int n = (int)a.cand_n[m];
     if (list_global) {
