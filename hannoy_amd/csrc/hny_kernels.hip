@@ -3451,6 +3451,9 @@ __host__ __device__ inline size_t apply_n8_lds_bytes(u32 row_stride, int SL) {
 #ifndef HNY_PRUNE_FILTER_MIN
 #define HNY_PRUNE_FILTER_MIN 40 // candidates left for the filter to be worth its second fetch
 #endif
+#ifndef HNY_PRUNE_TOUCH
+#define HNY_PRUNE_TOUCH 0
+#endif
 #ifndef HNY_PRUNE_FILTER_ROWS
 #define HNY_PRUNE_FILTER_ROWS 4 // rows of S the filter tests (the closest selected neighbours reject the most; 2: C4 prune 0.197 s, 4: 0.189, all: 0.190)
 #endif
@@ -3484,12 +3487,22 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, u64 *list, int n
   float4 nxt[NQ];
   float nxt_n = 0.f;
   // the row of candidate ci (this group's member of the chunk after next) on its way into `nxt`
+  u32 touched = 0u; // (sink of the touch loads below: never true, keeps them alive)
   auto prefetch = [&](int ci) __attribute__((always_inline)) {
     if (ci < n) {
       const u32 nx = (u32)(list[ci] & 0xFFFFFFFFull);
       load8(g.rows + (size_t)nx * g.row_stride, nxt);
       if (g.norms) nxt_n = g.norms[nx];
     }
+#if HNY_PRUNE_TOUCH
+    // and the row of the candidate one chunk further on its way into the L2: one dword per 128-B line (lane t of
+    // the group touches line t), so that the load above finds it there a chunk later instead of in HBM
+    if (ci + 8 < n) {
+      const u32 n2 = (u32)(list[ci + 8] & 0xFFFFFFFFull);
+      const u32 off = (u32)t * 128u;
+      if (off < g.row_stride) touched |= *reinterpret_cast<const u32 *>(g.rows + (size_t)n2 * g.row_stride + off) & 0x7FC00000u;
+    }
+#endif
   };
 #pragma unroll
   for (int k = 0; k < NQ; k++) nxt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -3621,6 +3634,9 @@ __device__ __forceinline__ int prune_n8_core(const GraphDev &g, u64 *list, int n
     // ---- the survivors through the chunks: rows [0, K0) are behind them
     for (; base < n && s_len < cap; base += 8) chunk(base, K0);
   }
+#if HNY_PRUNE_TOUCH
+  if (touched == 0x7FC00001u) evals++; // (never: bit 0 is masked off)
+#endif
   return s_len;
 }
 
