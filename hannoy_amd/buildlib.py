@@ -61,8 +61,15 @@ def build(force=False, verbose=False, out=None, tag=""):
     def run(job):
         if verbose:
             print(" ".join(job[1]), flush=True)
-        subprocess.check_call(job[1])
-        return job[0]
+        # (one retry: with eight compilers of a 5 000-line translation unit in flight, clang has been seen to
+        # die of a signal once in a few dozen builds; the same command succeeds when repeated)
+        for attempt in (1, 2):
+            rc = subprocess.call(job[1])
+            if rc == 0:
+                return job[0]
+            if attempt == 1:
+                print(f"[buildlib] {os.path.basename(job[0])}: compiler exit code {rc}, retrying once", file=sys.stderr, flush=True)
+        raise subprocess.CalledProcessError(rc, job[1])
     from concurrent.futures import ThreadPoolExecutor
     workers = max(1, min(len(jobs), int(os.environ.get("HNY_BUILD_JOBS", os.cpu_count() or 1))))
     with ThreadPoolExecutor(workers) as ex:
