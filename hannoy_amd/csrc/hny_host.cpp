@@ -284,9 +284,10 @@ struct hny_builder {
   DevBuf<u32> d_eps0;
   // k_walk_heap (walk_layer on heaps in HBM) for the members whose walk overflowed its tie pool: the list
   // of those members, a (count, work counter) pair per walk launch of a search call, the heaps
-  DevBuf<u32> d_pool_retry, d_pool_ctr;
+  DevBuf<u32> d_pool_retry, d_pool_retry2, d_pool_ctr;
   DevBuf<u64> d_heap_c, d_heap_r;
   uint32_t heap_grid = 0, heap_c_cap = 0, heap_r_cap = 0, pool_ctr_used = 0;
+  uint32_t heap_grid1 = 0, heap_c_cap1 = 0; // first tier of the build's retry path: many blocks, small heaps (0: one tier)
   u64 *heap_c_ptr = nullptr; // d_ops (borrowed while a batch is searched) or d_heap_c
   // the four large arrays of the hny_graph this build will export, allocated and touched page by page on a helper
   // thread WHILE the device builds (the host is idle then): finish() would otherwise pay the first touch of up to
@@ -1062,9 +1063,20 @@ static int create_impl(const hny_build_opts *opts, const hny_items *items, const
       HIP_TRY(b->d_heap_c.alloc((size_t)b->heap_grid * b->heap_c_cap));
       b->heap_c_ptr = b->d_heap_c.p;
     }
-    HIP_TRY(b->d_heap_r.alloc((size_t)b->heap_grid * b->heap_r_cap));
+    // Two tiers for the build's retry path: a `candidates` heap holds what a walk ACCEPTED and has not popped yet —
+    // a few times ef in practice — so the members first run on heaps of 2^18 entries, as many blocks as the area
+    // holds (up to 512), and only a member that outgrows such a heap is walked once more by the few blocks whose
+    // heaps hold every item (C4: 13).  One tier when the full heaps are no larger than that.
+    const uint64_t area = b->heap_c_ptr == b->d_ops.p ? b->d_ops.n : b->d_heap_c.n;
+    const uint64_t small_cap = (uint64_t)std::max(16, env_int("HNY_HEAP_SMALL_CAP", 1 << 18));
+    if ((uint64_t)b->heap_c_cap > small_cap) {
+      b->heap_c_cap1 = (uint32_t)small_cap;
+      b->heap_grid1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(slots, 512), area / small_cap));
+      HIP_TRY(b->d_pool_retry2.alloc(cand_rows));
+    }
+    HIP_TRY(b->d_heap_r.alloc((size_t)std::max(b->heap_grid, b->heap_grid1) * b->heap_r_cap));
     HIP_TRY(b->d_pool_retry.alloc(cand_rows));
-    HIP_TRY(b->d_pool_ctr.alloc(2 * 64));
+    HIP_TRY(b->d_pool_ctr.alloc(4 * 64)); // per walk launch: listed members, work counter — for each of the two tiers
   }
   HIP_TRY(b->d_deferred.alloc(b->max_ops));
   HIP_TRY(b->d_deferred_b.alloc(b->max_ops));
@@ -1320,13 +1332,13 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
   // the device and walked again by k_walk_heap, which reads the count itself — no host round trip
   auto launch_walk = [&](WalkArgs w, hipStream_t st) -> hipError_t {
     w.key_base = w.lo;
-    if (b->pool_ctr_used + 2 > b->d_pool_ctr.n) { // (more walk launches in one search call than counter pairs)
+    if (b->pool_ctr_used + 4 > b->d_pool_ctr.n) { // (more walk launches in one search call than counter sets)
       hipError_t e = hipMemsetAsync(b->d_pool_ctr.p, 0, b->d_pool_ctr.n * 4, st);
       if (e != hipSuccess) return e;
       b->pool_ctr_used = 0;
     }
     u32 *pc = b->d_pool_ctr.p + b->pool_ctr_used;
-    b->pool_ctr_used += 2;
+    b->pool_ctr_used += 4;
     const bool no_retry = env_int("HNY_NO_POOL_RETRY", 0) != 0; // tests: an overflow is an error again
     w.pool_retry = no_retry ? nullptr : b->d_pool_retry.p;
     w.n_pool_retry = pc;
@@ -1340,6 +1352,17 @@ int hny_builder_search(hny_builder *b, uint32_t lo, uint32_t hi, void *sel_dev) 
     h.heap_r = b->d_heap_r.p;
     h.heap_c_cap = b->heap_c_cap;
     h.heap_r_cap = b->heap_r_cap;
+    if (b->heap_grid1) { // first tier: small heaps, many blocks; what outgrows them is listed for the second
+      WalkArgs h1 = h;
+      h1.heap_c_cap = b->heap_c_cap1;
+      h1.pool_retry2 = b->d_pool_retry2.p;
+      h1.n_pool_retry2 = pc + 2;
+      e = hnyk_walk_heap(b->g, h1, b->shape, (int)std::min<uint32_t>(w.hi - w.lo, b->heap_grid1), st);
+      if (e != hipSuccess) return e;
+      h.pool_retry = b->d_pool_retry2.p;
+      h.n_pool_retry = pc + 2;
+      h.queue = pc + 3;
+    }
     return hnyk_walk_heap(b->g, h, b->shape, (int)std::min<uint32_t>(w.hi - w.lo, b->heap_grid), st);
   };
 

@@ -127,6 +127,11 @@ struct WalkArgs {
   // `res` as real heaps in HBM (heap_c / heap_r, [grid][cap] each), no pool, nothing to overflow but memory.
   u32 *pool_retry;   // members whose walk overflowed the 128-slot tie pool (null: count it as an error)
   u32 *n_pool_retry;
+  // k_walk_heap, first tier (many blocks, heaps of heap_c_cap < n entries): a member that outgrows its heap is
+  // listed here and walked once more by the second tier (few blocks, heaps that hold every item); null = the last
+  // tier: an overflow is an error
+  u32 *pool_retry2;
+  u32 *n_pool_retry2;
   u64 *heap_c, *heap_r;
   u32 heap_c_cap, heap_r_cap;
   u32 force_pool;    // test hook (HNY_POOL_FORCE_RETRY=n): treat every member with m % n == 0 as overflowed

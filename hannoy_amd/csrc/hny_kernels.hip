@@ -1794,23 +1794,22 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
   // compiler cannot see through (KA_FRESH: an empty asm that redefines it).  As a by-value copy they were all live
   // across the expansion loop — which uses a handful of them — and the register allocator parked 106 SGPRs in the
   // lanes of two VGPRs (v_writelane / v_readlane: ~20 reloads per expansion on the vector port, and two VGPRs of
-  // an 80-VGPR budget).  After a KA_FRESH a field is an s_load from the scalar cache at its next use.
+  // an 80-VGPR budget).  After a KA_FRESH a field (ak->field) is an s_load from the scalar cache at its next use.
   typedef const WalkArgs __attribute__((address_space(4))) *KArgs;
   KArgs ak = (KArgs)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() +
                      ((sizeof(GraphDev) + alignof(WalkArgs) - 1) / alignof(WalkArgs)) * alignof(WalkArgs));
   (void)a_in;
-#define a (*ak)
 #define KA_FRESH() asm volatile("" : "+s"(ak))
-  const int reader_mode = SP != 0 ? (RM ? 1 : 0) : a.reader_mode; // RM: the Reader's search (hny_builder_search_knn)
+  const int reader_mode = SP != 0 ? (RM ? 1 : 0) : ak->reader_mode; // RM: the Reader's search (hny_builder_search_knn)
   extern __shared__ __align__(16) unsigned char smem[];
   u64 *res = reinterpret_cast<u64 *>(smem);
-  u64 *pool = res + a.rcap;
+  u64 *pool = res + ak->rcap;
   if constexpr (SP == 0) {
     // a result set of more than 4 096 entries (a walk that never evicts, res_capacity in hny_host.cpp)
     // lives in HBM: the beam code only sees a pointer, WSYNC fences every address space
-    if (a.res_global) {
+    if (ak->res_global) {
       pool = res;
-      res = a.res_global + (size_t)blockIdx.x * a.rcap;
+      res = ak->res_global + (size_t)blockIdx.x * ak->rcap;
     }
   }
   u32 *nb_ids = reinterpret_cast<u32 *>(pool + HNY_POOL_CAP);
@@ -1826,7 +1825,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
 #endif
   s.res = res;
   s.pool = pool;
-  s.rcap = (int)a.rcap;
+  s.rcap = (int)ak->rcap;
   s.pool_over = 0;
   s.err = 0;
   s.res_len = 0;
@@ -1845,9 +1844,9 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
   // rows <= 1 KB never get an LDS table (the host passes vis_slots = 0 for them): say so at compile
   // time in the specialised kernels, so that the table's code and its six wave-uniform fields go
   constexpr bool NO_TAB = SP != 0 && NCH == 1;
-  visited_init(vis, a.bits + (size_t)blockIdx.x * a.bits_words, a.bits_words,
-               a.vlog + (size_t)blockIdx.x * a.log_cap, a.log_cap, eps + (BIG_EPS ? a.eps_cap : 64u),
-               NO_TAB ? 0u : a.vis_slots);
+  visited_init(vis, ak->bits + (size_t)blockIdx.x * ak->bits_words, ak->bits_words,
+               ak->vlog + (size_t)blockIdx.x * ak->log_cap, ak->log_cap, eps + (BIG_EPS ? ak->eps_cap : 64u),
+               NO_TAB ? 0u : ak->vis_slots);
   VisB vb;
   vb.tb = nullptr;
   vb.nb = 0;
@@ -1856,12 +1855,12 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
   vb.smask = 0;
   vb.off = 0;
   if constexpr (SHORT) {
-    if (a.vis_buckets) { // (behind eps; NO_TAB kernels have no other table there)
+    if (ak->vis_buckets) { // (behind eps; NO_TAB kernels have no other table there)
       vb.tb = reinterpret_cast<u64 *>(eps + 64);
-      vb.nb = a.vis_buckets;
-      vb.magic = a.vis_magic;
-      vb.shift = a.vis_shift;
-      vb.smask = a.vis_smask;
+      vb.nb = ak->vis_buckets;
+      vb.magic = ak->vis_magic;
+      vb.shift = ak->vis_shift;
+      vb.smask = ak->vis_smask;
       visb_clear(vb);
     }
   }
@@ -1874,40 +1873,40 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
     KA_FRESH();
     u32 m = 0;
     if (ln == 0) {
-      if (SP != 0 && a.xcd_tile) {
+      if (SP != 0 && ak->xcd_tile) {
         // Tiles of xcd_tile consecutive members (locality order) go round-robin to the 8 XCDs, each
         // with its own counter: the waves of one XCD (= one L2) work on neighbouring queries while all
         // eight stay inside the same window of the batch (= one Infinity-Cache footprint).  A wave
         // whose XCD has run out helps the next one.
-        const u32 T = a.xcd_tile, cnt_all = a.hi - a.lo;
+        const u32 T = ak->xcd_tile, cnt_all = ak->hi - ak->lo;
         m = 0xFFFFFFFFu;
         while (xq_dead < 8u) {
           const u32 x = (blockIdx.x + xq_dead) & 7u;
-          const u32 c = atomicAdd(a.queue + x, 1u);
+          const u32 c = atomicAdd(ak->queue + x, 1u);
           const u32 idx = ((c / T) * 8u + x) * T + (c % T);
           if (idx < cnt_all) {
-            m = a.lo + idx;
+            m = ak->lo + idx;
             break;
           }
           xq_dead++;
         }
       } else {
-        m = a.lo + atomicAdd(a.queue, 1u);
+        m = ak->lo + atomicAdd(ak->queue, 1u);
       }
       if constexpr (RM || SP == 0) // the Visitor's cancel probe (reader.rs:333), between queries
-        if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) m = 0xFFFFFFFFu;
+        if (ak->cancel && __hip_atomic_load(ak->cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) m = 0xFFFFFFFFu;
     }
     m = uni(m);
-    if (m >= a.hi) break;
-    if (a.perm) m = uni((u32)a.perm[m - a.lo]); // locality order; results stay indexed by member
+    if (m >= ak->hi) break;
+    if (ak->perm) m = uni((u32)ak->perm[m - ak->lo]); // locality order; results stay indexed by member
     const u64 evals_before = evals;
     const unsigned char *qrow;
     float qn = 0.f;
-    if (a.q_rows) {
-      qrow = a.q_rows + (size_t)m * a.q_stride;
-      if (a.q_norms) qn = a.q_norms[m];
+    if (ak->q_rows) {
+      qrow = ak->q_rows + (size_t)m * ak->q_stride;
+      if (ak->q_norms) qn = ak->q_norms[m];
     } else {
-      u32 qslot = a.q_slots[m];
+      u32 qslot = ak->q_slots[m];
       qrow = g.rows + (size_t)qslot * g.row_stride;
       if (g.norms) qn = g.norms[qslot];
     }
@@ -1924,24 +1923,24 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
 
     int n_eps;
     u32 start_layer;
-    if (a.first) { // :298 eps = all entry points
-      n_eps = (int)a.n_entry_points;
+    if (ak->first) { // :298 eps = all entry points
+      n_eps = (int)ak->n_entry_points;
       if (BIG_EPS) {
-        for (int i = ln; i < n_eps; i += 64) eps[i] = a.entry_points[i];
+        for (int i = ln; i < n_eps; i += 64) eps[i] = ak->entry_points[i];
       } else if (ln < n_eps) {
-        eps[ln] = a.entry_points[ln];
+        eps[ln] = ak->entry_points[ln];
       }
       start_layer = g.max_level;
-    } else if (a.eps_in) { // resume after a descend_only launch
+    } else if (ak->eps_in) { // resume after a descend_only launch
       n_eps = 1;
-      if (ln == 0) eps[0] = a.eps_in[m];
-      start_layer = a.layer;
+      if (ln == 0) eps[0] = ak->eps_in[m];
+      start_layer = ak->layer;
     } else { // :316-321 eps = what was selected on the layer above
-      const u64 *sl = a.sel + (size_t)m * a.sel_stride +
-                      (size_t)(a.batch_level - (a.layer + 1)) * (a.cap_sel + 1);
+      const u64 *sl = ak->sel + (size_t)m * ak->sel_stride +
+                      (size_t)(ak->batch_level - (ak->layer + 1)) * (ak->cap_sel + 1);
       n_eps = (int)sl[0];
       for (int i = ln; i < n_eps; i += 64) eps[i] = (u32)(sl[1 + i] & 0xFFFFFFFFull); // (more than 64: M > 64)
-      start_layer = a.layer;
+      start_layer = ak->layer;
     }
     // the lane-conditional stores above sit on the paths that define these two: without the readfirstlane the
     // compiler's uniformity analysis calls them divergent, and with them the layer loop's exit, `ef`, and
@@ -1951,12 +1950,12 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
     WSYNC();
     u64 lkey = 0;
     for (u32 layer = start_layer;; layer--) {
-      const bool last = (layer == a.layer);
-      if (last && a.descend_only) break;
+      const bool last = (layer == ak->layer);
+      if (last && ak->descend_only) break;
       if constexpr (SHORT)
-        walk_layer_short<LPR, RCN>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
+        walk_layer_short<LPR, RCN>(g, q, qn, layer, last ? (int)ak->ef : 1, eps, n_eps, s, vis, vb, nb_ids, nb_d, evals, err_iter, rb);
       else
-        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)a.ef : 1, eps, n_eps, s, vis, nb_ids,
+        walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, layer, last ? (int)ak->ef : 1, eps, n_eps, s, vis, nb_ids,
                                      nb_d, evals, err_iter, qrow, rb);
       KA_FRESH();
       if (last) break;
@@ -1968,7 +1967,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
       lkey = (lkey << 16) | (u64)((u32)g.upper_idx[closest] & 0xFFFFu);
       // walk_layer owns a fresh visited set; Reader::hnsw_search shares `path` across the greedy
       // layers and clears it once before layer 0 (reader.rs:731-743)
-      if (!reader_mode || layer == a.layer + 1) {
+      if (!reader_mode || layer == ak->layer + 1) {
         if (vis.log_over) log_over_cnt++;
         visited_clear(vis);
         visb_clear(vb);
@@ -1979,17 +1978,17 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
     // result.  Build walks hand the member to k_walk_heap (same launch arguments, heaps in HBM); without a
     // retry list (searches) the overflow is counted and fails the call.
     if constexpr (!RM) {
-      if (a.force_pool && m % a.force_pool == 0u) s.pool_over = 1u;
-      if (s.pool_over && a.pool_retry) {
-        if (ln == 0) a.pool_retry[atomicAdd(a.n_pool_retry, 1u)] = m;
+      if (ak->force_pool && m % ak->force_pool == 0u) s.pool_over = 1u;
+      if (s.pool_over && ak->pool_retry) {
+        if (ln == 0) ak->pool_retry[atomicAdd(ak->n_pool_retry, 1u)] = m;
         s.pool_over = 0;
         evals = evals_before; // the heap kernel counts this member's evaluations (the reference's number)
       }
     }
-    if (a.descend_only) { // (a batch whose level equals max_level has no greedy layer: eps stay)
+    if (ak->descend_only) { // (a batch whose level equals max_level has no greedy layer: eps stay)
       if (ln == 0) {
-        a.eps_out[m] = eps[0];
-        a.key_out[m - a.key_base] = lkey & 0xFFFFFFFFFFFFull;
+        ak->eps_out[m] = eps[0];
+        ak->key_out[m - ak->key_base] = lkey & 0xFFFFFFFFFFFFull;
       }
       WSYNC();
       continue;
@@ -1999,15 +1998,15 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
 #pragma unroll
       for (int c = 0; c < RCN; c++)
         if (ln + 64 * c < s.res_len)
-          a.cand[(size_t)m * a.rcap + 64 * c + ln] = (rb.r[c] & 0xFFFFFFFF00000000ull) | ((rb.r[c] >> 1) & 0x7FFFFFFFull);
+          ak->cand[(size_t)m * ak->rcap + 64 * c + ln] = (rb.r[c] & 0xFFFFFFFF00000000ull) | ((rb.r[c] >> 1) & 0x7FFFFFFFull);
     } else {
       for (int e = ln; e < s.res_len; e += 64) {
         u64 k = s.res[e];
-        a.cand[(size_t)m * a.rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+        ak->cand[(size_t)m * ak->rcap + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
       }
     }
     int total = s.res_len;
-    if (reader_mode && total < (int)a.knn_k) {
+    if (reader_mode && total < (int)ak->knn_k) {
       // Reader::hnsw_search exhaustive fallback (reader.rs:771-795): the walk got trapped in a
       // sub-graph with fewer than k items; restart from every item not seen yet (ascending id),
       // sharing the visited set, until opt.ef hits are collected.  Rare; written for clarity.
@@ -2034,7 +2033,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
         const u32 slot = ((wbase + (u32)l0) << 5) + (u32)__builtin_ctz(w0);
         pos = slot + 1;
         if (g.incremental && !g.has_vec[slot]) continue; // prefix_iter over Item keys: existing items
-        const int ef2 = (int)a.knn_ef > total ? (int)a.knn_ef - total : 0; // saturating_sub :786
+        const int ef2 = (int)ak->knn_ef > total ? (int)ak->knn_ef - total : 0; // saturating_sub :786
         if (ln == 0) eps[0] = slot;
         WSYNC();
         if constexpr (SHORT)
@@ -2042,7 +2041,7 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
         else
           walk_one_layer<LPR, NCH, BIG_EPS, RC, QN, LMERGE, PAGED>(g, q, qn, 0u, ef2, eps, 1, s, vis, nb_ids, nb_d, evals, err_iter, qrow, rb);
         KA_FRESH();
-        if (total + s.res_len > (int)a.rcap) {
+        if (total + s.res_len > (int)ak->rcap) {
           s.err = 1;
           break;
         }
@@ -2050,27 +2049,27 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
 #pragma unroll
           for (int c = 0; c < RCN; c++)
             if (ln + 64 * c < s.res_len)
-              a.cand[(size_t)m * a.rcap + total + 64 * c + ln] =
+              ak->cand[(size_t)m * ak->rcap + total + 64 * c + ln] =
                   (rb.r[c] & 0xFFFFFFFF00000000ull) | ((rb.r[c] >> 1) & 0x7FFFFFFFull);
         } else {
           for (int e = ln; e < s.res_len; e += 64) {
             u64 k = s.res[e];
-            a.cand[(size_t)m * a.rcap + total + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
+            ak->cand[(size_t)m * ak->rcap + total + e] = (k & 0xFFFFFFFF00000000ull) | ((k >> 1) & 0x7FFFFFFFull);
           }
         }
         total += s.res_len;
-        if (total >= (int)a.knn_ef) break; // :792-794
+        if (total >= (int)ak->knn_ef) break; // :792-794
       }
       // drain_asc(): sort everything that was collected
       __threadfence_block();
       WSYNC();
-      for (int e = ln; e < total; e += 64) s.res[e] = a.cand[(size_t)m * a.rcap + e];
+      for (int e = ln; e < total; e += 64) s.res[e] = ak->cand[(size_t)m * ak->rcap + e];
       WSYNC();
       for (int e = ln; e < total; e += 64) {
         const u64 mine = s.res[e];
         int rk = 0;
         for (int k2 = 0; k2 < total; k2++) rk += s.res[k2] < mine ? 1 : 0;
-        a.cand[(size_t)m * a.rcap + rk] = mine;
+        ak->cand[(size_t)m * ak->rcap + rk] = mine;
       }
       WSYNC();
     }
@@ -2078,12 +2077,12 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
       // a search whose tie pool overflowed: flagged instead of counted, the host repeats the query on the
       // heap-queue searcher (k_nns_filtered without a filter), which has no pool
       // (force_pool: tests send every k-th query that way)
-      if (reader_mode && a.pool_flag && (s.pool_over || (a.force_pool && m % a.force_pool == 0u))) {
+      if (reader_mode && ak->pool_flag && (s.pool_over || (ak->force_pool && m % ak->force_pool == 0u))) {
         total = (int)0xFFFFFFFEu;
         s.pool_over = 0;
       }
     }
-    if (ln == 0) a.cand_n[m] = (u32)total;
+    if (ln == 0) ak->cand_n[m] = (u32)total;
     if (vis.log_over) log_over_cnt++;
     visited_clear(vis);
     visb_clear(vb);
@@ -2112,7 +2111,6 @@ __global__ __launch_bounds__(64, (NCH == 1 && SP >= 4 && !RM && (RC == 1 || RC =
     if (err_iter) atomicAdd(&g.stats[ST_ERR_ITER], 1ull);
   }
 }
-#undef a
 #undef KA_FRESH
 
 // ---------------------------------------------------------------------------------------------
@@ -2589,6 +2587,7 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
     mi = uni(mi);
     if (mi >= n_mem) break;
     const u32 m = uni(a.pool_retry[mi]);
+    const u64 evals_before = evals;
     const unsigned char *qrow;
     float qn = 0.f;
     if (a.q_rows) { // a search: the query is not an item
@@ -2714,7 +2713,14 @@ __global__ __launch_bounds__(64, 4) void k_walk_heap(GraphDev g, WalkArgs a) {
         if (!st && ln == 0) a.cand_n[m] = total;
       }
     }
-    if (st) err = 1;
+    if (st) {
+      if (a.pool_retry2) { // first tier: this member outgrew its heap — the second tier has room for every item
+        if (ln == 0) a.pool_retry2[atomicAdd(a.n_pool_retry2, 1u)] = m;
+        evals = evals_before; // (counted by the walk that completes)
+      } else {
+        err = 1;
+      }
+    }
     if (vis.log_over) log_over_cnt++;
     visited_clear(vis);
     WSYNC();

@@ -1450,6 +1450,12 @@ def test_heap_walk_equals_oracle(orc, hny, monkeypatch, metric, n, dim, M, M0, e
         _same_graph(g, o)
         assert g.n_links_added == o.n_links_added
         assert g.n_evals_walk == o.n_evals_walk  # the discarded first walk of a handed-over member is not counted
+    # the retry path has two tiers (round 5): heaps of 2^18 entries on many blocks first, heaps that hold every item
+    # for the members that outgrow those.  Forty-entry first-tier heaps send most of the handed-over members on.
+    monkeypatch.setenv("HNY_HEAP_SMALL_CAP", "40")
+    g = hny.build(items, M=M, M0=M0, ef_construction=ef, **kw)
+    _same_graph(g, o)
+    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
 
 
 @pytest.mark.parametrize("tile", [16, 0])
