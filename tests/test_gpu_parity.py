@@ -1639,6 +1639,44 @@ def test_one_chunk_register_beam_equals_oracle(orc, hny, monkeypatch, metric, n,
     _same_graph(hny.build(items, M=M, M0=M0, ef_construction=ef, **kw), o)
 
 
+def test_export_arrays_prepared_during_the_build_and_recycled_on_request(orc, hny):
+    """hny_set_graph_cache (opt-in): hny_graph_free keeps the released export arrays for the next export; off (the
+    default) nothing is kept.  With and without it, on a builder whose export is large enough for the helper thread
+    that prepares the arrays during the build (>= 8 MB), repeated builds return the oracle's records — also when a
+    graph outlives the next build, when the build is reset before its finish(), and for a smaller index afterwards
+    (a cached array is only taken when it is not more than twice what is needed)."""
+    rng = np.random.default_rng(4)
+    n, dim = 70000, 32
+    cent = rng.uniform(-1, 1, (32, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 32, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds, items = _mk(orc, hny, 1, vecs, draw_levels(n, 16, seed=3))
+    kw = dict(M=16, M0=32, batch_frac=1.0, batch_max=8192)
+    o = orc.build(ds, ef=32, order=orc.ORDER_WAVE, threads=8, **kw)
+    small_ds, small_items = _mk(orc, hny, 1, vecs[:9000], draw_levels(9000, 16, seed=3))
+    small_o = orc.build(small_ds, ef=32, order=orc.ORDER_WAVE, threads=8, **kw)
+    for cache in (1 << 30, 0):
+        hny.set_graph_cache(cache)
+        try:
+            with hny.Builder(items, ef_construction=32, **kw) as b:
+                b.run()
+                g1 = b.finish()
+                b.reset()
+                b.next_batch()  # a build that is abandoned after its first batch was handed out ...
+                b.reset()       # ... leaves its prepared arrays to the next one
+                b.run()
+                g2 = b.finish()
+                _same_graph(g1, o)  # g1 is still alive and untouched
+                _same_graph(g2, o)
+                del g1
+                b.reset()
+                b.run()
+                _same_graph(b.finish(), o)
+            del g2
+            _same_graph(hny.build(small_items, ef_construction=32, **kw), small_o)
+        finally:
+            hny.set_graph_cache(0)
+
+
 def test_m0_limits_are_refused_loudly(orc, hny):
     """include/hannoy_amd.h: M <= M0 <= 1024 (strict mode too — fresh builds since round 4, updates since round 5):
     HNY_ERR_UNSUPPORTED on a machine WITH a GPU too (no silent clamp)."""
