@@ -134,3 +134,24 @@ def test_c1_readme_config_on_the_oracle(orc):
     c1 = orc.encode_vectors(orc.COSINE, q1)
     ids, dists, cnt = orc.search(ds, seq, c1, orc.make_headers(orc.COSINE, 3, c1), k=1, ef_search=10)
     assert cnt[0] == 1 and dists[0, 0] == 0.0
+
+
+@pytest.mark.parametrize("metric,dim,order", [(0, 24, "x86"), (3, 256, "wave"), (1, 128, "wave")])
+def test_threaded_link_phase_of_a_batch_is_the_sequential_one(orc, metric, dim, order):
+    """Batches of 256 members and more replay their add_link calls on several threads (round 5): every thread
+    walks the whole sequence in batch order and performs the calls whose TARGET it owns, so per target the order is
+    the sequential one.  The raw lists — insertion order, distances, duplicates and all — and the evaluation and
+    link counters must be those of the one-thread build, for any thread count, with lists that overflow and
+    re-prune (M0 = 12 on 5 000 clustered points) and with the AVX2 form of the wave-order reduction."""
+    rng = np.random.default_rng(dim)
+    n = 5000
+    cent = rng.uniform(-1, 1, (12, dim)).astype(np.float32)
+    vecs = (cent[rng.integers(0, 12, n)] + 0.25 * rng.standard_normal((n, dim))).astype(np.float32)
+    ds = orc.Dataset.from_f32(metric, vecs, draw_levels(n, 6, 3))
+    kw = dict(M=6, M0=12, ef=32, order=orc.ORDER_X86 if order == "x86" else orc.ORDER_WAVE, batch_frac=1.0, batch_max=2048)
+    one = orc.build(ds, threads=1, **kw)
+    for t in (2, 5, 8):
+        g = orc.build(ds, threads=t, **kw)
+        assert np.array_equal(g.raw_offsets, one.raw_offsets) and np.array_equal(g.raw_nbrs, one.raw_nbrs)
+        assert np.array_equal(g.raw_dists.view(np.uint32), one.raw_dists.view(np.uint32))
+        assert (g.n_links_added, g.n_distance_evals, g.n_evals_walk) == (one.n_links_added, one.n_distance_evals, one.n_evals_walk)
