@@ -98,27 +98,3 @@ def test_gpus_2_self_launched_ranks_build_over_gloo_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert j["ranks_seen"] == 2 and j["launcher"] == "self" and j["replicas_identical"] is True and j["n_collectives"] > 0
-
-
-def _visible_gpus():
-    import torch
-    return torch.cuda.device_count()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["native", "self"])
-def test_gpus_n_over_real_rccl_when_the_box_has_the_gpus(mode):
-    """`bench.py --gpus N [--native]` with N = min(visible GPUs, 8) distinct devices over RCCL — the command the
-    driver issues for the scaling bench.  Auto-skips on a one-GPU box."""
-    n = min(_visible_gpus(), 8)
-    if n < 2:
-        pytest.skip("one GPU visible")
-    env = dict(_clean_env(), HNY_MGPU_VERIFY="1")
-    env.pop("HNY_MGPU_SHIM", None)
-    cmd = [sys.executable, BENCH, "--gpus", str(n)] + (["--native"] if mode == "native" else []) + \
-          ["--items", "200000", "--dim", "128", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-recall", "--queries", "0"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
-    assert j["n_gpus"] == n and j["ranks_seen"] == n and j["replicas_identical"] is True
-    assert sorted(j["devices"]) == list(range(n)) and j["n_collectives"] > 0 and j["value"] > 0

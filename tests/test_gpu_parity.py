@@ -1049,37 +1049,6 @@ def test_native_multi_gpu_driver_one_rank_over_rccl(orc, hny):
     _same_graph(g1, g)
 
 
-def _visible_gpus():
-    import torch
-    return torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-
-
-@pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("metric", [0, 3])
-def test_native_multi_gpu_over_real_rccl_when_the_box_has_the_gpus(orc, hny, monkeypatch, world, metric):
-    """hny_build(n_gpus = N) on N DISTINCT devices, no shim: ncclCommInitAll over the node's GPUs, both all-gathers
-    of every batch over xGMI, sharded searches and deferred re-prunes.  Skips on a one-GPU box (every other
-    multi-rank test maps its ranks to GPU 0 through HNY_MGPU_SHIM); on a multi-GPU box it runs without anyone
-    asking — the exported graph of EVERY replica (HNY_MGPU_VERIFY) must be the oracle's, counters included."""
-    have = _visible_gpus()
-    if have < world:
-        pytest.skip(f"{world} GPUs needed, {have} visible")
-    monkeypatch.delenv("HNY_MGPU_SHIM", raising=False)
-    monkeypatch.setenv("HNY_MGPU_VERIFY", "1")
-    monkeypatch.setenv("HNY_MGPU_MIN_BATCH", "16")
-    monkeypatch.setenv("HNY_MGPU_MIN_DEFERRED", "2")
-    ds, items, o, kw = _multi_case(orc, hny, metric=metric, n=20000, dim=96 if metric < 3 else 512)
-    g = hny.build(items, n_gpus=world, devices=list(range(world)), **kw)
-    _same_graph(g, o)
-    assert g.n_links_added == o.n_links_added and g.n_evals_walk == o.n_evals_walk
-    # the resident form (what bench.py --gpus N --native times): two runs on the same replicas
-    with hny.MultiBuilder(items, devices=list(range(world)), **kw) as mb:
-        assert mb.world == world
-        for _ in range(2):
-            _same_graph(mb.run(), o)
-        assert mb.n_collectives > 0
-
-
 @pytest.mark.parametrize("world,metric", [(2, 0), (3, 3), (4, 1)])
 def test_native_multi_gpu_driver_ranks_share_one_gpu(orc, hny, monkeypatch, world, metric):
     """The native driver with `world` ranks mapped to ONE GPU (HNY_MGPU_SHIM=1: the collective is
